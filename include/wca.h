@@ -1,0 +1,182 @@
+/*
+ * wca.h -- C ABI of libwca.so, the MI355X (gfx950) forced-alignment engine.
+ *
+ * This is the drop-in boundary for the hot path of 30stomercury/whisper-char-alignment.
+ * The reference has no FFI layer of its own (it is pure Python calling openai-whisper); the
+ * boundary is therefore the set of Python functions below, and each entry point here names the
+ * reference interface it replaces (file:line in the reference repository):
+ *
+ *   wca_log_mel            dataset.py:46-48, dataset.py:107-109, README.md:101-103
+ *                          (whisper.pad_or_trim + whisper.log_mel_spectrogram)
+ *   wca_get_attentions     timing.py:45-67   get_attentions(): teacher-forced forward with every
+ *                          cross-attention QK captured (timing.py:50-58), [:max_frames] slice,
+ *                          median_filter, *qk_scale, softmax (timing.py:63-66); logits returned
+ *   wca_median_filter      timing.py:65      whisper.timing.median_filter
+ *   wca_filter_attention   timing.py:13-43   filter_attention(): head scores + tuple-ordered top-k
+ *                          (+ metrics.py:99-111 coverage_penalty)
+ *   wca_force_align        timing.py:69-103  force_align() up to and including dtw(-matrix):
+ *                          aggregation "mean" (timing.py:84-89) / "topk" (timing.py:91-97), the
+ *                          [len(sot_sequence):-1] slice (timing.py:102), DTW + backtrace (timing.py:103)
+ *   wca_dtw                timing.py:103     whisper.timing.dtw -> dtw_cpu + backtrace
+ *   wca_align_batch        infer_ali.py:93-101 + dataset.py:47-48: the whole per-utterance pipeline
+ *                          (log-mel -> forward+capture -> medfilt/softmax -> scores/top-k ->
+ *                          aggregate -> DTW) for a micro-batch of utterances, results = the frame
+ *                          at which the DTW path enters every token row (timing.py:110-111 `jumps`)
+ *
+ * Conventions
+ *   - plain C types only; no torch / HIP types in signatures (streams are passed as void*).
+ *   - `_dev` pointers are device (HBM) pointers owned by the caller; `_host` pointers are host memory.
+ *   - every function returns 0 on success or a negative wca_status; wca_last_error() gives a
+ *     thread-local description. Nothing throws across this boundary.
+ *   - one engine <-> one GPU <-> one stream <-> one host thread. Engines are independent.
+ *   - limits mirror infer_ali.py:25-26,79: n_tok <= 448, max_frames <= 1500 (WCA_ERR_TOO_LONG).
+ */
+#ifndef WCA_H_
+#define WCA_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wca_engine wca_engine;
+
+typedef enum {
+  WCA_OK = 0,
+  WCA_ERR_INVALID = -1,   /* bad argument / shape                                  */
+  WCA_ERR_TOO_LONG = -2,  /* n_tok > 448 or max_frames > 1500 (infer_ali.py:79)    */
+  WCA_ERR_HIP = -3,       /* a HIP runtime call failed                             */
+  WCA_ERR_STATE = -4,     /* weights missing / engine not finalized                */
+  WCA_ERR_NOMEM = -5
+} wca_status;
+
+/* whisper.model.ModelDimensions */
+typedef struct {
+  int32_t n_mels;
+  int32_t n_audio_ctx;    /* 1500 */
+  int32_t n_audio_state;
+  int32_t n_audio_head;
+  int32_t n_audio_layer;
+  int32_t n_vocab;
+  int32_t n_text_ctx;     /* 448 */
+  int32_t n_text_state;
+  int32_t n_text_head;
+  int32_t n_text_layer;
+} wca_model_dims;
+
+enum { WCA_DTYPE_F32 = 0, WCA_DTYPE_F16 = 1 };
+enum { WCA_AGGR_MEAN = 0, WCA_AGGR_TOPK = 1 };
+
+/* options of filter_attention / force_align (timing.py:13, timing.py:69-78) */
+typedef struct {
+  int32_t aggregation;    /* WCA_AGGR_MEAN | WCA_AGGR_TOPK                          */
+  int32_t topk;           /* > 0 required for WCA_AGGR_TOPK (timing.py:92)          */
+  float w_colnorm;        /* default 1.0                                           */
+  float w_rownorm;        /* default 1.0                                           */
+  float w_coverage;       /* default 0.0                                           */
+  int32_t sot_len;        /* len(tokenizer.sot_sequence): rows dropped at the top   */
+  int32_t medfilt_width;  /* odd; used by wca_align_batch / wca_get_attentions      */
+  float qk_scale;         /* 1.0 in the reference (infer_ali.py:45)                 */
+} wca_align_opts;
+
+const char* wca_last_error(void);
+int wca_version(void);
+
+/* ---- engine lifetime ------------------------------------------------------------------------ */
+int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out);
+void wca_engine_destroy(wca_engine* e);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = engine-owned stream */
+int wca_engine_set_stream(wca_engine* e, void* hip_stream);
+int wca_engine_synchronize(wca_engine* e);
+
+/* Weights in openai-whisper state_dict naming ("encoder.blocks.0.attn.query.weight", ...), host
+ * memory, row-major. Also accepts the auxiliary table "mel_filters" [n_mels][201] (whisper's
+ * assets/mel_filters.npz). Call wca_finalize_weights once after the last tensor. */
+int wca_load_weight(wca_engine* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
+int wca_finalize_weights(wca_engine* e);
+
+/* ---- hot path, one reference function per entry point ---------------------------------------- */
+
+/* pcm_dev: [batch][pcm_stride] f32 (values beyond n_samples are ignored = zero padding to 30 s);
+ * mel_out_dev: [batch][n_mels][3000] f32. */
+int wca_log_mel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host, int batch,
+                float* mel_out_dev);
+
+/* mel_dev [batch][n_mels][3000] f32; tokens_dev [batch][n_tok] int64 (already sot..eot framed,
+ * infer_ali.py:69-76; shorter utterances padded with any valid token id, true lengths in n_tok_host,
+ * NULL = all n_tok); max_frames_host [batch].
+ * weights_out_dev: [batch][L][H][n_tok][F] f32 with F = max over the batch of max_frames (rows/cols
+ * beyond an utterance's own n_tok/max_frames are unspecified); logits_out_dev: [batch][n_tok][n_vocab]
+ * f32 or NULL. */
+int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* tokens_dev, int batch, int n_tok,
+                       const int32_t* n_tok_host, const int32_t* max_frames_host, int medfilt_width, float qk_scale,
+                       float* weights_out_dev, float* logits_out_dev);
+
+/* in/out [rows][F] f32 device, reflect padding, width odd */
+int wca_median_filter(wca_engine* e, const float* in_dev, float* out_dev, int64_t rows, int F, int width);
+
+/* attns_dev [L][H][n][F] f32 (already softmaxed). scores_host [L*H]; sel_idx_host/sel_score_host
+ * [min(topk, L*H)] ascending by (score, (l,h)) -- element i is head l = idx / H, h = idx % H. */
+int wca_filter_attention(wca_engine* e, const float* attns_dev, int L, int H, int n, int F, int topk, float w_colnorm,
+                         float w_rownorm, float w_coverage, float* scores_host, int32_t* sel_idx_host,
+                         float* sel_score_host);
+
+/* ws_dev [L][H][n][F] f32. Outputs (host): matrix_host [(n - sot_len - 1)][F] f32 (the sliced,
+ * NOT negated matrix, timing.py:102); text_idx_host / time_idx_host [n - sot_len - 1 + F] int32 with
+ * *path_len_host valid entries; sel_idx_host / sel_score_host [topk] (topk mode only, may be NULL). */
+int wca_force_align(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const wca_align_opts* opts,
+                    float* matrix_host, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host,
+                    int32_t* sel_idx_host, float* sel_score_host);
+
+/* DTW on the NEGATED matrix exactly like `dtw(-matrix)`; matrix_host [N][M] f32 row-major.
+ * text_idx_host / time_idx_host capacity N + M. */
+int wca_dtw(wca_engine* e, const float* matrix_host, int N, int M, int32_t* text_idx_host, int32_t* time_idx_host,
+            int32_t* path_len_host);
+
+/* Same for P independent problems already in HBM (probe_oracle.py:88-90: one DTW per head).
+ * matrix_dev [P][N][M]; jump_frame_host [P][N]: frame at which the path enters each row. */
+int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int M, int32_t* jump_frame_host);
+
+/* Fused per-utterance pipeline for a micro-batch (the north-star hot path).
+ * pcm_dev [batch][pcm_stride] f32; tokens_dev [batch][n_tok_max] int64; n_tok_host, n_samples_host,
+ * max_frames_host [batch].
+ * jump_frame_host [batch][n_tok_max]: for utterance b, entries [0, n_tok[b] - sot_len - 1) are the frame
+ * index at which the DTW path enters that text row (jump_times * 50, timing.py:110-111).
+ * sel_idx_host [batch][topk] may be NULL. */
+int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
+                    const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host,
+                    const int32_t* max_frames_host, int batch, const wca_align_opts* opts, int32_t* jump_frame_host,
+                    int32_t* sel_idx_host);
+
+/* Same pipeline, but only enqueues the work on the engine stream (no host sync, results stay in the
+ * engine's pinned staging buffers until wca_align_batch_fetch). Used by bench.py to time with HIP events. */
+int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
+                            const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host,
+                            const int32_t* max_frames_host, int batch, const wca_align_opts* opts);
+int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int32_t* jump_frame_host,
+                          int32_t* sel_idx_host);
+
+/* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
+/* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device, out f32 device */
+int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
+                  int N, int K, int gelu, int out_mode);
+/* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL */
+int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
+                       float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
+int wca_test_layernorm(wca_engine* e, const float* x_dev, const float* g_dev, const float* b_dev, void* out_f16_dev,
+                       int rows, int d);
+/* encoder only: mel_dev [batch][n_mels][3000] f32 -> xa_out_dev [batch][1500][d] f32 (ln_post output) */
+int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_out_dev);
+
+/* timing of the last wca_align_batch* call, milliseconds per stage measured with HIP events on the
+ * engine stream: [0] log-mel, [1] encoder, [2] cross K/V projection, [3] decoder, [4] head stats,
+ * [5] top-k + aggregate, [6] DTW, [7] total. Valid after a synchronize/fetch. */
+int wca_last_stage_ms(wca_engine* e, float* ms8);
+/* enable/disable per-stage event recording (default off: no extra events on the stream) */
+int wca_set_profiling(wca_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WCA_H_ */

@@ -1,0 +1,24 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def wca():
+    """The product package (hyphenated directory name => importlib)."""
+    return importlib.import_module("whisper-char-alignment_amd")
+
+
+@pytest.fixture(scope="session")
+def lib(wca):
+    return wca._lib.load()

@@ -1,0 +1,281 @@
+"""Kernel-level parity tests (run on the MI355X with `-m gpu`): every HIP kernel is called through the
+C ABI (ctypes) and compared with a CPU reference -- the oracle for the integer/order-statistic kernels
+(bit-exact), plain PyTorch fp32 for the floating-point kernels (tolerance stated per test)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+@pytest.fixture(scope="module")
+def eng(wca):
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    dims = wca.ModelDimensions(80, 1500, 384, 6, 2, 51865, 448, 384, 6, 2)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2)
+    m.load_state_dict(syn.random_state_dict(dims, seed=1))
+    m._bind_stream()
+    return m
+
+
+# ------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1500, 1152, 384), (77, 130, 64), (128, 128, 64), (3000, 384, 256)])
+@pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
+def test_gemm(eng, lib, wca, M, N, K, mode):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).half()
+    w = (torch.randn(N, K, generator=g) * 0.1).half()
+    bias = torch.randn(N, generator=g)
+    ref = a.float() @ w.float().T + bias
+    ad, wd, bd = a.cuda(), w.cuda(), bias.cuda()
+    if mode == "f16" or mode == "f16_gelu":
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        gelu = int(mode == "f16_gelu")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0))
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+        torch.cuda.synchronize()
+        # f16 output rounding: 2^-11 relative + fp32 accumulation order
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+    elif mode == "f32":
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 1))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    else:
+        base = torch.randn(M, N, generator=g)
+        out = base.clone().cuda()
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu(), base + ref, rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_asymmetric_identity(eng, lib, wca):
+    """A = I with an asymmetric W catches a transposed / permuted C write."""
+    M = N = K = 128
+    a = torch.eye(M, K).half()
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).half()
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a.cuda()), _vp(w.cuda()), None, _vp(out), M, N, K, 0, 1))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), w.float().T.contiguous())
+
+
+# ------------------------------------------------------------------------------- attention
+def _attn_ref(q, k, v, H, causal):
+    B, nq, d = q.shape
+    nk = k.shape[1]
+    qh = q.float().view(B, nq, H, 64).permute(0, 2, 1, 3)
+    kh = k.float().view(B, nk, H, 64).permute(0, 2, 1, 3)
+    vh = v.float().view(B, nk, H, 64).permute(0, 2, 1, 3)
+    qk = (qh @ kh.transpose(-1, -2)) * 0.125
+    s = qk.clone()
+    if causal:
+        s = s + torch.full((nq, nk), float("-inf")).triu_(1)
+    o = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, nq, d)
+    return o, qk
+
+
+@pytest.mark.parametrize("B,H,nq,nk,causal,cap_cols", [
+    (2, 3, 150, 200, 0, 0), (1, 2, 70, 70, 1, 0), (2, 6, 69, 1500, 0, 500), (1, 4, 448, 1500, 0, 1500),
+    (1, 2, 300, 300, 1, 0), (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0)])
+def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
+    g = torch.Generator().manual_seed(nq * 13 + nk)
+    d = H * 64
+    q = torch.randn(B, nq, d, generator=g).half()
+    k = torch.randn(B, nk, d, generator=g).half()
+    v = torch.randn(B, nk, d, generator=g).half()
+    # a few large logits so the online-softmax rescale path is exercised
+    q[:, nq // 2, :64] *= 4.0
+    o_ref, qk_ref = _attn_ref(q, k, v, H, causal)
+    out = torch.full((B, nq, d), float("nan"), dtype=torch.float16, device="cuda")
+    cap_ld = (cap_cols + 3) & ~3
+    cap = torch.full((B, H, nq, max(cap_ld, 4)), float("nan"), device="cuda") if cap_cols else None
+    wca._lib.check(lib.wca_test_attention(eng._h, _vp(q.cuda()), _vp(k.cuda()), _vp(v.cuda()), _vp(out), _vp(cap),
+                                          cap_ld, cap_cols, B, H, nq, nk, causal))
+    torch.cuda.synchronize()
+    # P is rounded to f16 before P.V and the output is f16: ~1e-3 relative
+    torch.testing.assert_close(out.float().cpu(), o_ref, rtol=4e-3, atol=4e-3)
+    if cap_cols:
+        got = cap.cpu()[..., :cap_cols]
+        # f16 operands are exact, fp32 accumulation over 64 terms
+        torch.testing.assert_close(got, qk_ref[..., :cap_cols], rtol=1e-4, atol=1e-4)
+
+
+def test_layernorm(eng, lib, wca):
+    g = torch.Generator().manual_seed(3)
+    for d in (384, 1024, 1280):
+        x = torch.randn(37, d, generator=g) * 3 + 1
+        gm, bt = torch.randn(d, generator=g), torch.randn(d, generator=g)
+        out = torch.empty(37, d, dtype=torch.float16, device="cuda")
+        wca._lib.check(lib.wca_test_layernorm(eng._h, _vp(x.cuda()), _vp(gm.cuda()), _vp(bt.cuda()), _vp(out), 37, d))
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5)
+        torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
+
+
+# ------------------------------------------------------------------------------- DTW (bit-exact)
+def _dtw_gpu(eng, lib, wca, m):
+    m = np.ascontiguousarray(m, dtype=np.float32)
+    N, M = m.shape
+    ti = np.zeros(N + M, dtype=np.int32)
+    tj = np.zeros(N + M, dtype=np.int32)
+    n = C.c_int32(0)
+    wca._lib.check(lib.wca_dtw(eng._h, m.ctypes.data_as(C.POINTER(C.c_float)), N, M, ti.ctypes.data_as(C.POINTER(C.c_int32)),
+                               tj.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(n)))
+    return ti[:n.value].astype(np.int64), tj[:n.value].astype(np.int64)
+
+
+def _dtw_cases():
+    rng = np.random.default_rng(0)
+    cases = []
+    for (N, M) in [(1, 1), (1, 7), (5, 1), (3, 3), (65, 500), (64, 500), (66, 145), (36, 145), (129, 700), (444, 1500), (200, 37),
+                   (448, 100)]:
+        cases.append(("rand%dx%d" % (N, M), rng.random((N, M), dtype=np.float32)))
+    cases.append(("const", np.full((40, 90), 0.25, dtype=np.float32)))
+    cases.append(("zeros", np.zeros((17, 33), dtype=np.float32)))
+    cases.append(("ints", rng.integers(0, 3, size=(65, 300)).astype(np.float32)))
+    cases.append(("ints_tall", rng.integers(0, 2, size=(130, 90)).astype(np.float32)))
+    sm = torch.softmax(torch.from_numpy(rng.standard_normal((65, 500)).astype(np.float32)) * 3, -1).numpy()
+    cases.append(("softmax", sm))
+    diag = np.full((50, 400), 1e-4, dtype=np.float32)
+    for i in range(50):
+        diag[i, i * 8:(i + 1) * 8] = 0.5
+    cases.append(("diagonal", diag))
+    return cases
+
+
+@pytest.mark.parametrize("name,m", _dtw_cases(), ids=[c[0] for c in _dtw_cases()])
+def test_dtw_bit_exact(eng, lib, wca, name, m):
+    from oracle import timing_ref
+    ti, tj = _dtw_gpu(eng, lib, wca, m)
+    ref = timing_ref.dtw(-torch.from_numpy(m))
+    assert np.array_equal(ti, ref[0]) and np.array_equal(tj, ref[1])
+
+
+def test_dtw_batch_jump_frames(eng, lib, wca):
+    from oracle import timing_ref
+    rng = np.random.default_rng(5)
+    P, N, M = 7, 65, 333
+    mats = rng.random((P, N, M), dtype=np.float32)
+    jf = np.zeros((P, N), dtype=np.int32)
+    md = torch.from_numpy(mats).cuda()
+    wca._lib.check(lib.wca_dtw_batch_dev(eng._h, _vp(md), P, N, M, jf.ctypes.data_as(C.POINTER(C.c_int32))))
+    for p in range(P):
+        ti, tj = timing_ref.dtw(-torch.from_numpy(mats[p]))
+        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+        assert np.array_equal(jf[p], tj[jumps])
+
+
+# ------------------------------------------------------------------------------- median filter (bit-exact)
+@pytest.mark.parametrize("F,w", [(500, 3), (500, 7), (145, 5), (1500, 7), (10, 9), (3, 7), (64, 1), (777, 11), (40, 33)])
+def test_median_filter_bit_exact(eng, lib, wca, F, w):
+    from oracle import timing_ref
+    g = torch.Generator().manual_seed(F + w)
+    x = torch.randn(37, F, generator=g)
+    x[3, : min(F, 20)] = 1.5  # ties
+    out = torch.empty_like(x).cuda()
+    wca._lib.check(lib.wca_median_filter(eng._h, _vp(x.cuda()), _vp(out), 37, F, w))
+    torch.cuda.synchronize()
+    ref = timing_ref.median_filter(x.view(1, 1, 37, F), w).reshape(37, F)
+    assert torch.equal(out.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------- filter_attention / force_align
+def _fa_gpu(eng, lib, wca, A, topk, wc, wr, wv):
+    L, H, n, F = A.shape
+    sc = np.zeros(L * H, dtype=np.float32)
+    keff = min(topk, L * H)
+    idx = np.zeros(keff, dtype=np.int32)
+    ss = np.zeros(keff, dtype=np.float32)
+    wca._lib.check(lib.wca_filter_attention(eng._h, _vp(A.cuda().contiguous()), L, H, n, F, topk, wc, wr, wv,
+                                            sc.ctypes.data_as(C.POINTER(C.c_float)), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            ss.ctypes.data_as(C.POINTER(C.c_float))))
+    return sc, idx, ss
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 12, 50), (6, 8, 69, 500), (2, 3, 448, 130), (3, 2, 30, 1500)])
+@pytest.mark.parametrize("wts", [(1.0, 1.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (1.0, 1.0, 1.0)])
+def test_filter_attention(eng, lib, wca, shape, wts):
+    from oracle import timing_ref
+    g = torch.Generator().manual_seed(sum(shape))
+    A = torch.softmax(torch.randn(*shape, generator=g) * 3, -1)
+    topk = 5
+    sc, idx, ss = _fa_gpu(eng, lib, wca, A, topk, *wts)
+    _, ref = timing_ref.filter_attention(A, topk, *wts)
+    H = shape[1]
+    ref_scores_all = {(l, h): None for l in range(shape[0]) for h in range(H)}
+    # scores: fp32 reductions in a different order -> 1e-5 relative
+    full = timing_ref.filter_attention(A, shape[0] * H, *wts)[1]
+    for s, (l, h), _ in full:
+        assert abs(sc[l * H + h] - s) <= 2e-5 * max(1.0, abs(s))
+    # selection: identical unless two scores are closer than the reduction-order noise
+    ref_idx = [l * H + h for _, (l, h), _ in ref]
+    gaps = np.diff(sorted(s for s, _, _ in full))
+    if gaps.min() > 1e-4:
+        assert list(idx) == ref_idx
+
+
+@pytest.mark.parametrize("aggr,topk", [("mean", -1), ("topk", 10), ("topk", 3)])
+def test_force_align_matrix_and_path(eng, lib, wca, aggr, topk):
+    from oracle import timing_ref
+    g = torch.Generator().manual_seed(11)
+    L, H, n, F = 6, 8, 69, 500
+    A = torch.softmax(torch.randn(L, H, n, F, generator=g) * 4, -1)
+    opts = eng.make_opts(aggregation=aggr, topk=topk, sot_len=3)
+    N = n - 3 - 1
+    mat = np.zeros((N, F), dtype=np.float32)
+    ti = np.zeros(N + F, dtype=np.int32)
+    tj = np.zeros(N + F, dtype=np.int32)
+    plen = C.c_int32(0)
+    k = max(topk, 1)
+    sel = np.zeros(k, dtype=np.int32)
+    ssc = np.zeros(k, dtype=np.float32)
+    wca._lib.check(lib.wca_force_align(eng._h, _vp(A.cuda()), L, H, n, F, C.byref(opts), mat.ctypes.data_as(C.POINTER(C.c_float)),
+                                       ti.ctypes.data_as(C.POINTER(C.c_int32)), tj.ctypes.data_as(C.POINTER(C.c_int32)),
+                                       C.byref(plen), sel.ctypes.data_as(C.POINTER(C.c_int32)), ssc.ctypes.data_as(C.POINTER(C.c_float))))
+    ref_m, ref_scores = timing_ref.aggregate(A, aggr, topk)
+    ref_m = ref_m[3:-1]
+    # aggregated matrix: fp32, different reduction order for the column norms
+    np.testing.assert_allclose(mat, ref_m.numpy(), rtol=2e-5, atol=1e-7)
+    # DTW of the GPU matrix must be bit-exact w.r.t. the oracle DTW of the SAME matrix
+    ref_path = timing_ref.dtw(-torch.from_numpy(mat))
+    assert np.array_equal(ti[:plen.value], ref_path[0]) and np.array_equal(tj[:plen.value], ref_path[1])
+    if aggr == "topk":
+        assert list(sel[:topk]) == [l * H + h for _, (l, h), _ in ref_scores]
+
+
+# ------------------------------------------------------------------------------- log-mel
+def test_logmel_vs_oracle(eng, wca):
+    from oracle import whisper_ref
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    audio_mod = importlib.import_module("whisper-char-alignment_amd.audio")
+    filt = audio_mod.mel_filters(80)
+    pcm = np.stack([syn.synth_audio(0, 160000), syn.synth_audio(1, 160000)])
+    pcm[1, 100000:] = 0.0
+    got = eng.log_mel(torch.from_numpy(pcm).cuda(), n_samples=[160000, 100000]).cpu()
+    ref = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), filt)
+    # fp32 DFT by direct summation vs FFT: values are log10/4-scaled, 1e-4 absolute
+    assert got.shape == ref.shape == (2, 80, 3000)
+    assert (got - ref).abs().max().item() < 2e-4
+
+
+def test_logmel_full_length_and_sample(eng, wca):
+    from oracle import whisper_ref
+    import os
+    audio_mod = importlib.import_module("whisper-char-alignment_amd.audio")
+    filt = audio_mod.mel_filters(80)
+    rng = np.random.default_rng(7)
+    full = (0.05 * rng.standard_normal(480000)).astype(np.float32)  # exercises the reflect padding at 30 s
+    sample = np.load(os.path.join(os.path.dirname(__file__), "golden", "sample_pcm_int16.npy")).astype(np.float32) / 32768.0
+    for pcm in (full, sample):
+        got = eng.log_mel(torch.from_numpy(pcm).cuda()).cpu()
+        ref = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), filt)
+        assert (got - ref).abs().max().item() < 2e-4

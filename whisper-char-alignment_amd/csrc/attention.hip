@@ -1,0 +1,241 @@
+// Multi-head attention for gfx950 with head_dim 64 (all Whisper sizes), one kernel for
+//   * encoder self-attention            (reference: timing.py:58 -> whisper AudioEncoder blocks)
+//   * decoder causal self-attention
+//   * decoder cross-attention with CAPTURE of the pre-softmax logits qk = (q*s)(k*s)^T, which is
+//     exactly what the reference's forward hooks collect (timing.py:50-55, outs[-1]).
+//
+// Structure: 256-thread workgroup = 4 waves, each wave owns 32 query rows (two 16-row subtiles);
+// 64-key K/V tiles are streamed HBM -> LDS with LDS-DMA (double buffered). Scores are computed
+// TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_f16) so a query row lives on one lane column and
+// the online-softmax statistics are lane-local (+2 cross-lane steps). P^T feeds the second MFMA
+// (O^T = V^T P^T) straight from registers; V^T fragments come from ds_read_b64_tr_b16.
+#include "kernels.h"
+#include "wca_common.h"
+
+namespace wca {
+
+namespace {
+
+constexpr int KT = 64;               // keys per tile
+constexpr int TILE = 64 * 64;        // f16 elements of one K or V tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ half4 tr_read4(const half_t* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WCA_LDS s16x4*)(p));
+  return __builtin_bit_cast(half4, r);
+}
+
+template <bool CAUSAL, bool CAPTURE>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);  // [buf][K tile | V tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q_blk = blockIdx.x * 128;
+  const int q_wave = q_blk + wave * 32;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = fr][dd = ks*32 + 8*fg + j]
+  half8 qf[2][2];
+  int qrow[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    qrow[sub] = q_wave + sub * 16 + fr;
+    const int qc = qrow[sub] < a.nq ? qrow[sub] : a.nq - 1;
+    const half_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + h * 64 + fg * 8;
+    qf[sub][0] = *reinterpret_cast<const half8*>(qp);
+    qf[sub][1] = *reinterpret_cast<const half8*>(qp + 32);
+  }
+
+  int nk_eff = a.nk;
+  if (CAUSAL) {
+    const int qhi = q_blk + 128;
+    nk_eff = qhi < a.nk ? qhi : a.nk;
+  }
+  const int nkt = (nk_eff + KT - 1) / KT;
+
+  const half_t* Kb = a.K + (long)b * a.k_bs + h * 64;
+  const half_t* Vb = a.V + (long)b * a.v_bs + h * 64;
+
+  auto stage = [&](int buf, int kt) {
+    half_t* Kt = lds + buf * (2 * TILE);
+    half_t* Vt = Kt + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (wave * 2 + i) * 8;
+      const int r = rbase + (lane >> 3);
+      int key = kt * KT + r;
+      key = key < a.nk ? key : a.nk - 1;
+      const int ck = (lane & 7) ^ swz128(r);
+      const int cv = (lane & 7) ^ (r & 6);
+      glds16(Kb + (long)key * a.k_rs + ck * 8, Kt + rbase * 64);
+      glds16(Vb + (long)key * a.v_rs + cv * 8, Vt + rbase * 64);
+    }
+  };
+
+  f32x4 ot[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};
+  float l_run[2] = {0.f, 0.f};
+
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
+    const half_t* Kt = lds + cur * (2 * TILE);
+    const half_t* Vt = Kt + TILE;
+
+    // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r]
+    f32x4 st[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 kf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = t * 16 + fr;
+        kf[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((ks * 4 + fg) ^ swz128(r)) << 3));
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t], qf[s][ks], st[s][t], 0, 0, 0);
+    }
+
+    half8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int key4 = kt * KT + t * 16 + 4 * fg;
+        f32x4 v = st[s][t] * a.scale;
+        if (CAPTURE) {
+          if (key4 < a.cap_cols && qrow[s] < a.nq) {
+            float* cp = a.cap + (long)b * a.cap_bs + (long)h * a.cap_hs + (long)qrow[s] * a.cap_ld + key4;
+            *reinterpret_cast<f32x4*>(cp) = v;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = key4 + r;
+          bool dead = key >= a.nk;
+          if (CAUSAL) dead = dead || (key > qrow[s]);
+          v[r] = dead ? -INFINITY : v[r];
+          mx = fmaxf(mx, v[r]);
+        }
+        st[s][t] = v;
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[s], mx);
+      // rows past nq under the causal mask can be fully masked in the first tile: keep them finite
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = exp2f((m_run[s] - m_use) * LOG2E);
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f((st[s][t][r] - m_use) * LOG2E);
+          st[s][t][r] = p;
+          rs += p;
+        }
+      rs += __shfl_xor(rs, 16);
+      rs += __shfl_xor(rs, 32);
+      l_run[s] = l_run[s] * alpha + rs;
+      m_run[s] = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
+      // P^T fragments (B operand of O^T = V^T P^T): k-step ks2 covers score tiles 2*ks2, 2*ks2+1
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        half8 f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f[r] = (half_t)st[s][2 * k2][r];
+          f[4 + r] = (half_t)st[s][2 * k2 + 1][r];
+        }
+        pf[s][k2] = f;
+      }
+    }
+
+    // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr],
+    // k order matches pf: j<4 -> key (2*k2)*16 + 4*fg + j, j>=4 -> key (2*k2+1)*16 + 4*fg + (j-4).
+    {
+      const int qd = fr >> 2, pd = fr & 3;  // this lane supplies row qd, columns 4*pd..4*pd+3 of its group's block
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + 4 * pd;
+        const int c = d >> 3, w = d & 7;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int key0 = (2 * k2) * 16 + 4 * fg + qd;
+          const int key1 = key0 + 16;
+          const half4 v0 = tr_read4(Vt + key0 * 64 + ((c ^ (key0 & 6)) << 3) + w);
+          const half4 v1 = tr_read4(Vt + key1 * 64 + ((c ^ (key1 & 6)) << 3) + w);
+          half8 vf;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            vf[r] = v0[r];
+            vf[4 + r] = v1[r];
+          }
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[s][k2], ot[s][dt], 0, 0, 0);
+        }
+      }
+    }
+    wait_vm0();
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: ot[s][dt][r] = O[q = fr][d = dt*16 + 4*fg + r]
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (qrow[s] >= a.nq) continue;
+    const float inv = 1.0f / l_run[s];
+    half_t* op = a.O + (long)b * a.o_bs + (long)qrow[s] * a.o_rs + h * 64 + 4 * fg;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      half4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)(ot[s][dt][r] * inv);
+      *reinterpret_cast<half4*>(op + dt * 16) = o;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+  if (a.nq <= 0 || a.B <= 0) return hipSuccess;
+  if (a.nk <= 0) return hipErrorInvalidValue;
+  if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;
+  if (a.cap != nullptr && ((a.cap_ld % 4) != 0 || a.cap_ld < ((a.cap_cols + 3) & ~3))) return hipErrorInvalidValue;
+  dim3 grid((a.nq + 127) / 128, a.H, a.B), block(256);
+  const size_t shmem = 2 * 2 * TILE * sizeof(half_t);  // 32 KiB
+  const bool cap = a.cap != nullptr && a.cap_cols > 0;
+  if (a.causal) {
+    if (cap) hipLaunchKernelGGL((attn_kernel<true, true>), grid, block, shmem, s, a);
+    else hipLaunchKernelGGL((attn_kernel<true, false>), grid, block, shmem, s, a);
+  } else {
+    if (cap) hipLaunchKernelGGL((attn_kernel<false, true>), grid, block, shmem, s, a);
+    else hipLaunchKernelGGL((attn_kernel<false, false>), grid, block, shmem, s, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace wca

@@ -1,0 +1,112 @@
+// Row-wise small ops of the Whisper forward (HBM-bound, one wave per row, vectorised I/O).
+//   layernorm_f16 : whisper.model.LayerNorm (fp32 statistics, eps 1e-5) feeding an f16 GEMM operand
+//   embed         : token_embedding[tokens] + positional_embedding[:n]   (TextDecoder.forward)
+#include "kernels.h"
+#include "wca_common.h"
+
+namespace wca {
+
+namespace {
+
+// d % 128 == 0, d <= 128 * MAXP (Whisper: 384..1280)
+constexpr int MAXP = 10;
+
+__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, half_t* __restrict__ out,
+                                                            int rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nper = d >> 7;  // float2 per lane
+  const f32x2* xr = reinterpret_cast<const f32x2*>(x + (long)row * d);
+  f32x2 v[MAXP];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (i < nper) {
+      v[i] = xr[i * 64 + lane];
+      s += v[i][0] + v[i][1];
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (i < nper) {
+      const float a = v[i][0] - mean, b = v[i][1] - mean;
+      q += a * a + b * b;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  const f32x2* g2 = reinterpret_cast<const f32x2*>(gamma);
+  const f32x2* b2 = reinterpret_cast<const f32x2*>(beta);
+  half2_* o2 = reinterpret_cast<half2_*>(out + (long)row * d);
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    if (i < nper) {
+      const f32x2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
+      half2_ o;
+      o[0] = (half_t)((v[i][0] - mean) * rstd * g[0] + bb[0]);
+      o[1] = (half_t)((v[i][1] - mean) * rstd * g[1] + bb[1]);
+      o2[i * 64 + lane] = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const half_t* __restrict__ tok_emb,
+                                                    const float* __restrict__ pos_emb, float* __restrict__ x, int B, int n,
+                                                    int d) {
+  const int row = blockIdx.x;  // b*n + i
+  const int i = row % n;
+  const long tok = tokens[row];
+  const half_t* e = tok_emb + tok * d;
+  const float* p = pos_emb + (long)i * d;
+  float* o = x + (long)row * d;
+  for (int c = threadIdx.x; c < d; c += blockDim.x) o[c] = (float)e[c] + p[c];
+}
+
+__global__ void fill_f16_kernel(half_t* p, size_t n, float v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t st = (size_t)gridDim.x * blockDim.x;
+  const half_t h = (half_t)v;
+  for (; i < n; i += st) p[i] = h;
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) out[i] = (half_t)in[i];
+}
+
+}  // namespace
+
+hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int rows, int d,
+                                float eps, hipStream_t s) {
+  if (rows <= 0) return hipSuccess;
+  if ((d % 128) != 0 || d > 128 * MAXP) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(layernorm_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, d, eps);
+  return hipGetLastError();
+}
+
+hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x, int B, int n,
+                        int d, hipStream_t s) {
+  if (B * n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(embed_kernel, dim3(B * n), dim3(256), 0, s, tokens, tok_emb, pos_emb, x, B, n, d);
+  return hipGetLastError();
+}
+
+hipError_t launch_fill_f16(half_t* p, size_t n, float v, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(fill_f16_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+  return hipGetLastError();
+}
+
+hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+  return hipGetLastError();
+}
+
+}  // namespace wca

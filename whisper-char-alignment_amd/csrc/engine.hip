@@ -1,0 +1,1257 @@
+// libwca.so engine: weight residency, activation arena, forward orchestration and the C ABI of
+// include/wca.h.  One engine = one MI355X = one HIP stream = one host thread.
+//
+// Data layout in HBM (per engine, B = max_batch, d = n_state, L = decoder layers):
+//   weights   f16 [N][K] row-major (torch Linear layout), q/k/v fused to [3d][d]; the cross-attention
+//             key/value projections of ALL decoder layers fused to one [L*2*d][d] matrix so that the
+//             encoder output is projected by a single large MFMA GEMM; conv kernels re-ordered to
+//             [d][tap*C + c] so the conv stem is a GEMM over overlapping time-major windows.
+//   residual  f32 [B*1500][d] (encoder), f32 [B*n][d] (decoder); GEMM operands are f16.
+//   capture   f32 [B][L*H][n_max][Fpad]  pre-softmax cross-attention logits (timing.py:50-55)
+//   weights_ws f32 [B][L*H][n_max][Fmax] filtered+softmaxed maps (timing.py:63-66)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/wca.h"
+#include "kernels.h"
+
+using namespace wca;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIPCHK(expr)                                                                              \
+  do {                                                                                            \
+    hipError_t _e = (expr);                                                                       \
+    if (_e != hipSuccess) return fail(WCA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+constexpr int N_FRAMES = 3000, N_CTX = 1500, MAX_TOK = 448, N_BIN = 201, N_FFT = 400;
+constexpr int META_SLOTS = 16;
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct GrowBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t ensure(size_t need) {
+    if (need <= bytes) return hipSuccess;
+    if (p) {
+      hipError_t e = hipFree(p);
+      if (e != hipSuccess) return e;
+      p = nullptr;
+      bytes = 0;
+    }
+    need = align_up(need, 1 << 20);
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) return e;
+    bytes = need;
+    return hipSuccess;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+struct LayerW {
+  float *ln1_g, *ln1_b;
+  half_t* qkv_w;
+  float* qkv_b;
+  half_t* out_w;
+  float* out_b;
+  float *ln2_g, *ln2_b;  // mlp_ln
+  half_t* fc1_w;
+  float* fc1_b;
+  half_t* fc2_w;
+  float* fc2_b;
+  // decoder only
+  float *lnc_g, *lnc_b;
+  half_t* cq_w;
+  float* cq_b;
+  half_t* co_w;
+  float* co_b;
+};
+
+}  // namespace
+
+struct wca_engine {
+  wca_model_dims dims;
+  int device = 0;
+  int max_batch = 1;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  bool finalized = false;
+  bool have_filters = false;
+  bool profiling = false;
+  std::set<std::string> loaded;
+
+  // ---- weights
+  char* wslab = nullptr;
+  size_t wslab_bytes = 0, wslab_used = 0;
+  int k1pad = 0;  // padded K of the conv1 GEMM
+  half_t *conv1_w = nullptr, *conv2_w = nullptr;
+  float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *lnpost_g = nullptr, *lnpost_b = nullptr;
+  std::vector<LayerW> enc, dec;
+  half_t* tok_emb = nullptr;
+  float *dec_pos = nullptr, *lnf_g = nullptr, *lnf_b = nullptr;
+  half_t* kv_w = nullptr;
+  float* kv_b = nullptr;
+  float *mel_filters = nullptr, *window = nullptr, *twiddle = nullptr;
+  int *filt_lo = nullptr, *filt_hi = nullptr;
+
+  // ---- fixed activation arena (sized for max_batch)
+  char* aslab = nullptr;
+  float* mel_scratch = nullptr;
+  unsigned* gmax = nullptr;
+  float* mel_f32 = nullptr;
+  half_t* mel_tm = nullptr;
+  half_t* h1pad = nullptr;
+  float* x = nullptr;      // [B*1500][d]
+  half_t* xn = nullptr;    // [B*1500][d]
+  half_t* qkv = nullptr;   // [B*1500][3d]
+  half_t* att = nullptr;   // [B*1500][d]
+  half_t* hid = nullptr;   // [B*1500][4d]
+  half_t* kv = nullptr;    // [B*1500][L*2*d]
+  float* xd = nullptr;     // [B*448][d]
+  half_t* xdn = nullptr;
+  half_t* qkv_d = nullptr;
+  half_t* att_d = nullptr;
+  half_t* q_d = nullptr;
+  half_t* hid_d = nullptr;
+  int* meta_dev = nullptr;   // META_SLOTS x 4 x max_batch ints: n_samples, n_tok, n_frames, dtwN
+  int* meta_host = nullptr;  // pinned mirror
+  int meta_slot = 0;
+
+  // ---- run-time sized buffers
+  GrowBuf cap, wws, colnorm, scores, sel, selsc, matrix, trace, path, pathlen, jump, tmp0, tmp1;
+  int* res_host = nullptr;  // pinned results staging
+  size_t res_host_ints = 0;
+  int last_topk = 0, last_ntok_max = 0, last_batch = 0;
+
+  hipEvent_t ev[9] = {};
+  bool ev_valid = false;
+  float stage_ms[8] = {};
+};
+
+namespace {
+
+template <typename T>
+T* carve(char*& cur, size_t count, size_t align = 256) {
+  uintptr_t p = reinterpret_cast<uintptr_t>(cur);
+  p = (p + align - 1) / align * align;
+  T* r = reinterpret_cast<T*>(p);
+  cur = reinterpret_cast<char*>(p + count * sizeof(T));
+  return r;
+}
+
+// ---- weight slab layout (two passes: size, then carve)
+size_t layout_weights(wca_engine* e, char* base) {
+  const wca_model_dims& D = e->dims;
+  const int d = D.n_audio_state, dt = D.n_text_state;
+  char* cur = base;
+  e->k1pad = (int)align_up((size_t)3 * D.n_mels, 64);
+  e->conv1_w = carve<half_t>(cur, (size_t)d * e->k1pad);
+  e->conv1_b = carve<float>(cur, d);
+  e->conv2_w = carve<half_t>(cur, (size_t)d * 3 * d);
+  e->conv2_b = carve<float>(cur, d);
+  e->enc_pos = carve<float>(cur, (size_t)N_CTX * d);
+  e->lnpost_g = carve<float>(cur, d);
+  e->lnpost_b = carve<float>(cur, d);
+  e->enc.resize(D.n_audio_layer);
+  for (auto& l : e->enc) {
+    l.ln1_g = carve<float>(cur, d);
+    l.ln1_b = carve<float>(cur, d);
+    l.qkv_w = carve<half_t>(cur, (size_t)3 * d * d);
+    l.qkv_b = carve<float>(cur, 3 * d);
+    l.out_w = carve<half_t>(cur, (size_t)d * d);
+    l.out_b = carve<float>(cur, d);
+    l.ln2_g = carve<float>(cur, d);
+    l.ln2_b = carve<float>(cur, d);
+    l.fc1_w = carve<half_t>(cur, (size_t)4 * d * d);
+    l.fc1_b = carve<float>(cur, 4 * d);
+    l.fc2_w = carve<half_t>(cur, (size_t)4 * d * d);
+    l.fc2_b = carve<float>(cur, d);
+    l.lnc_g = l.lnc_b = nullptr;
+    l.cq_w = l.co_w = nullptr;
+    l.cq_b = l.co_b = nullptr;
+  }
+  e->tok_emb = carve<half_t>(cur, (size_t)D.n_vocab * dt);
+  e->dec_pos = carve<float>(cur, (size_t)D.n_text_ctx * dt);
+  e->lnf_g = carve<float>(cur, dt);
+  e->lnf_b = carve<float>(cur, dt);
+  e->kv_w = carve<half_t>(cur, (size_t)D.n_text_layer * 2 * dt * d);
+  e->kv_b = carve<float>(cur, (size_t)D.n_text_layer * 2 * dt);
+  e->dec.resize(D.n_text_layer);
+  for (auto& l : e->dec) {
+    l.ln1_g = carve<float>(cur, dt);
+    l.ln1_b = carve<float>(cur, dt);
+    l.qkv_w = carve<half_t>(cur, (size_t)3 * dt * dt);
+    l.qkv_b = carve<float>(cur, 3 * dt);
+    l.out_w = carve<half_t>(cur, (size_t)dt * dt);
+    l.out_b = carve<float>(cur, dt);
+    l.lnc_g = carve<float>(cur, dt);
+    l.lnc_b = carve<float>(cur, dt);
+    l.cq_w = carve<half_t>(cur, (size_t)dt * dt);
+    l.cq_b = carve<float>(cur, dt);
+    l.co_w = carve<half_t>(cur, (size_t)dt * dt);
+    l.co_b = carve<float>(cur, dt);
+    l.ln2_g = carve<float>(cur, dt);
+    l.ln2_b = carve<float>(cur, dt);
+    l.fc1_w = carve<half_t>(cur, (size_t)4 * dt * dt);
+    l.fc1_b = carve<float>(cur, 4 * dt);
+    l.fc2_w = carve<half_t>(cur, (size_t)4 * dt * dt);
+    l.fc2_b = carve<float>(cur, dt);
+  }
+  e->mel_filters = carve<float>(cur, (size_t)D.n_mels * N_BIN);
+  e->window = carve<float>(cur, N_FFT);
+  e->twiddle = carve<float>(cur, 2 * N_FFT);
+  e->filt_lo = carve<int>(cur, D.n_mels);
+  e->filt_hi = carve<int>(cur, D.n_mels);
+  return (size_t)(cur - base) + 4096;
+}
+
+size_t layout_arena(wca_engine* e, char* base) {
+  const wca_model_dims& D = e->dims;
+  const size_t B = e->max_batch, d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
+  char* cur = base;
+  e->mel_scratch = carve<float>(cur, B * D.n_mels * N_FRAMES);
+  e->gmax = carve<unsigned>(cur, B);
+  e->mel_f32 = carve<float>(cur, B * D.n_mels * N_FRAMES);
+  e->mel_tm = carve<half_t>(cur, B * (N_FRAMES + 2) * D.n_mels + 4096);
+  e->h1pad = carve<half_t>(cur, B * (N_FRAMES + 2) * d + 4096);
+  e->x = carve<float>(cur, B * N_CTX * d);
+  e->xn = carve<half_t>(cur, B * N_CTX * d);
+  e->qkv = carve<half_t>(cur, B * N_CTX * 3 * d);
+  e->att = carve<half_t>(cur, B * N_CTX * d);
+  e->hid = carve<half_t>(cur, B * N_CTX * 4 * d);
+  e->kv = carve<half_t>(cur, B * N_CTX * L * 2 * dt);
+  e->xd = carve<float>(cur, B * MAX_TOK * dt);
+  e->xdn = carve<half_t>(cur, B * MAX_TOK * dt);
+  e->qkv_d = carve<half_t>(cur, B * MAX_TOK * 3 * dt);
+  e->att_d = carve<half_t>(cur, B * MAX_TOK * dt);
+  e->q_d = carve<half_t>(cur, B * MAX_TOK * dt);
+  e->hid_d = carve<half_t>(cur, B * MAX_TOK * 4 * dt);
+  e->meta_dev = carve<int>(cur, (size_t)META_SLOTS * 4 * B);
+  return (size_t)(cur - base) + 4096;
+}
+
+hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
+                int N, int K, int gelu, int out_mode) {
+  GemmArgs g{};
+  g.A = A;
+  g.lda = lda;
+  g.W = W;
+  g.ldw = ldw;
+  g.bias = bias;
+  g.C = C;
+  g.ldc = ldc;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.gelu = gelu;
+  g.out_mode = out_mode;
+  return launch_gemm(g, s);
+}
+
+// upload helpers: convert host tensor (f32 or f16) into device f16 / f32
+int put_f16(half_t* dst, const void* src, int dtype, size_t n) {
+  std::vector<half_t> tmp(n);
+  if (dtype == WCA_DTYPE_F32) {
+    const float* s = static_cast<const float*>(src);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (half_t)s[i];
+  } else {
+    memcpy(tmp.data(), src, n * sizeof(half_t));
+  }
+  HIPCHK(hipMemcpy(dst, tmp.data(), n * sizeof(half_t), hipMemcpyHostToDevice));
+  return WCA_OK;
+}
+int put_f32(float* dst, const void* src, int dtype, size_t n) {
+  if (dtype == WCA_DTYPE_F32) {
+    HIPCHK(hipMemcpy(dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> tmp(n);
+    const half_t* s = static_cast<const half_t*>(src);
+    for (size_t i = 0; i < n; ++i) tmp[i] = (float)s[i];
+    HIPCHK(hipMemcpy(dst, tmp.data(), n * sizeof(float), hipMemcpyHostToDevice));
+  }
+  return WCA_OK;
+}
+inline float host_val(const void* src, int dtype, size_t i) {
+  return dtype == WCA_DTYPE_F32 ? static_cast<const float*>(src)[i] : (float)static_cast<const half_t*>(src)[i];
+}
+
+// conv weight [out][in][3] -> f16 [out][kpad] with column tap*in + c
+int put_conv(half_t* dst, const void* src, int dtype, int out, int in, int kpad) {
+  std::vector<half_t> tmp((size_t)out * kpad, (half_t)0.f);
+  for (int n = 0; n < out; ++n)
+    for (int c = 0; c < in; ++c)
+      for (int t = 0; t < 3; ++t) tmp[(size_t)n * kpad + t * in + c] = (half_t)host_val(src, dtype, ((size_t)n * in + c) * 3 + t);
+  HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  return WCA_OK;
+}
+
+size_t numel(const int64_t* shape, int ndim) {
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  return n;
+}
+
+int load_block_tensor(wca_engine* e, LayerW& l, bool is_dec, int li, const std::string& rest, const void* p, int dtype,
+                      size_t n, int d) {
+  const size_t dd = (size_t)d * d;
+  auto expect = [&](size_t want) -> bool { return n == want; };
+#define WANT(cnt) \
+  if (!expect(cnt)) return fail(WCA_ERR_INVALID, "weight %s: expected %zu elements, got %zu", rest.c_str(), (size_t)(cnt), n)
+  if (rest == "attn.query.weight") { WANT(dd); return put_f16(l.qkv_w, p, dtype, n); }
+  if (rest == "attn.query.bias") { WANT(d); return put_f32(l.qkv_b, p, dtype, n); }
+  if (rest == "attn.key.weight") { WANT(dd); return put_f16(l.qkv_w + dd, p, dtype, n); }
+  if (rest == "attn.value.weight") { WANT(dd); return put_f16(l.qkv_w + 2 * dd, p, dtype, n); }
+  if (rest == "attn.value.bias") { WANT(d); return put_f32(l.qkv_b + 2 * d, p, dtype, n); }
+  if (rest == "attn.out.weight") { WANT(dd); return put_f16(l.out_w, p, dtype, n); }
+  if (rest == "attn.out.bias") { WANT(d); return put_f32(l.out_b, p, dtype, n); }
+  if (rest == "attn_ln.weight") { WANT(d); return put_f32(l.ln1_g, p, dtype, n); }
+  if (rest == "attn_ln.bias") { WANT(d); return put_f32(l.ln1_b, p, dtype, n); }
+  if (rest == "mlp.0.weight") { WANT(4 * dd); return put_f16(l.fc1_w, p, dtype, n); }
+  if (rest == "mlp.0.bias") { WANT(4 * (size_t)d); return put_f32(l.fc1_b, p, dtype, n); }
+  if (rest == "mlp.2.weight") { WANT(4 * dd); return put_f16(l.fc2_w, p, dtype, n); }
+  if (rest == "mlp.2.bias") { WANT(d); return put_f32(l.fc2_b, p, dtype, n); }
+  if (rest == "mlp_ln.weight") { WANT(d); return put_f32(l.ln2_g, p, dtype, n); }
+  if (rest == "mlp_ln.bias") { WANT(d); return put_f32(l.ln2_b, p, dtype, n); }
+  if (is_dec) {
+    if (rest == "cross_attn.query.weight") { WANT(dd); return put_f16(l.cq_w, p, dtype, n); }
+    if (rest == "cross_attn.query.bias") { WANT(d); return put_f32(l.cq_b, p, dtype, n); }
+    if (rest == "cross_attn.key.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li) * dd, p, dtype, n); }
+    if (rest == "cross_attn.value.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li + 1) * dd, p, dtype, n); }
+    if (rest == "cross_attn.value.bias") { WANT(d); return put_f32(e->kv_b + (size_t)(2 * li + 1) * d, p, dtype, n); }
+    if (rest == "cross_attn.out.weight") { WANT(dd); return put_f16(l.co_w, p, dtype, n); }
+    if (rest == "cross_attn.out.bias") { WANT(d); return put_f32(l.co_b, p, dtype, n); }
+    if (rest == "cross_attn_ln.weight") { WANT(d); return put_f32(l.lnc_g, p, dtype, n); }
+    if (rest == "cross_attn_ln.bias") { WANT(d); return put_f32(l.lnc_b, p, dtype, n); }
+  }
+#undef WANT
+  return 1;  // unknown (ignored)
+}
+
+void record(wca_engine* e, int i) {
+  if (e->profiling && e->ev_valid) (void)hipEventRecord(e->ev[i], e->stream);
+}
+
+// ---- encoder: mel_tm (f16 time-major) -> xn = ln_post(x) (f16) and optionally x (f32)
+int run_encoder(wca_engine* e, int B) {
+  const wca_model_dims& D = e->dims;
+  const int d = D.n_audio_state, H = D.n_audio_head;
+  hipStream_t s = e->stream;
+  {
+    GemmArgs g{};
+    g.A = e->mel_tm;
+    g.lda = D.n_mels;
+    g.a_rows_per_batch = N_FRAMES;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * D.n_mels;
+    g.W = e->conv1_w;
+    g.ldw = e->k1pad;
+    g.bias = e->conv1_b;
+    g.C = e->h1pad + d;  // output frame t lands in padded row t + 1
+    g.ldc = d;
+    g.c_rows_per_batch = N_FRAMES;
+    g.c_batch_stride = (long)(N_FRAMES + 2) * d;
+    g.M = B * N_FRAMES;
+    g.N = d;
+    g.K = e->k1pad;
+    g.gelu = 1;
+    g.out_mode = 0;
+    HIPCHK(launch_gemm(g, s));
+  }
+  {
+    GemmArgs g{};
+    g.A = e->h1pad;
+    g.lda = 2 * d;  // stride 2
+    g.a_rows_per_batch = N_CTX;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * d;
+    g.W = e->conv2_w;
+    g.ldw = 3 * d;
+    g.bias = e->conv2_b;
+    g.C = e->x;
+    g.ldc = d;
+    g.pos = e->enc_pos;
+    g.pos_period = N_CTX;
+    g.M = B * N_CTX;
+    g.N = d;
+    g.K = 3 * d;
+    g.gelu = 1;
+    g.out_mode = 1;
+    HIPCHK(launch_gemm(g, s));
+  }
+  const int M = B * N_CTX;
+  const float scale = 1.0f / std::sqrt((float)(d / H));
+  for (int li = 0; li < D.n_audio_layer; ++li) {
+    const LayerW& l = e->enc[li];
+    HIPCHK(launch_layernorm_f16(e->x, l.ln1_g, l.ln1_b, e->xn, M, d, 1e-5f, s));
+    HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0));
+    AttnArgs a{};
+    a.Q = e->qkv;
+    a.K = e->qkv + d;
+    a.V = e->qkv + 2 * d;
+    a.q_bs = a.k_bs = a.v_bs = (long)N_CTX * 3 * d;
+    a.q_rs = a.k_rs = a.v_rs = 3 * d;
+    a.O = e->att;
+    a.o_bs = (long)N_CTX * d;
+    a.o_rs = d;
+    a.nq = N_CTX;
+    a.nk = N_CTX;
+    a.H = H;
+    a.B = B;
+    a.scale = scale;
+    a.causal = 0;
+    HIPCHK(launch_attention(a, s));
+    HIPCHK(gemm(s, e->att, d, l.out_w, d, l.out_b, e->x, d, M, d, d, 0, 2));
+    HIPCHK(launch_layernorm_f16(e->x, l.ln2_g, l.ln2_b, e->xn, M, d, 1e-5f, s));
+    HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0));
+    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2));
+  }
+  HIPCHK(launch_layernorm_f16(e->x, e->lnpost_g, e->lnpost_b, e->xn, M, d, 1e-5f, s));
+  return WCA_OK;
+}
+
+// cross-attention K/V of every decoder layer in one GEMM: kv[b*1500 + t][(2l + {0,1})*dt + c]
+int run_cross_kv(wca_engine* e, int B) {
+  const wca_model_dims& D = e->dims;
+  const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
+  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, e->kv, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0));
+  return WCA_OK;
+}
+
+// decoder with capture. tokens_dev [B][n]; capture -> cap [B][L*H][n][Fpad] (first Fcap keys)
+int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out) {
+  const wca_model_dims& D = e->dims;
+  const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
+  hipStream_t s = e->stream;
+  const int M = B * n;
+  const float scale = 1.0f / std::sqrt((float)(dt / H));
+  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, s));
+  for (int li = 0; li < L; ++li) {
+    const LayerW& l = e->dec[li];
+    HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, M, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, M, 3 * dt, dt, 0, 0));
+    {
+      AttnArgs a{};
+      a.Q = e->qkv_d;
+      a.K = e->qkv_d + dt;
+      a.V = e->qkv_d + 2 * dt;
+      a.q_bs = a.k_bs = a.v_bs = (long)n * 3 * dt;
+      a.q_rs = a.k_rs = a.v_rs = 3 * dt;
+      a.O = e->att_d;
+      a.o_bs = (long)n * dt;
+      a.o_rs = dt;
+      a.nq = n;
+      a.nk = n;
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 1;
+      HIPCHK(launch_attention(a, s));
+    }
+    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, M, dt, dt, 0, 2));
+    HIPCHK(launch_layernorm_f16(e->xd, l.lnc_g, l.lnc_b, e->xdn, M, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, M, dt, dt, 0, 0));
+    {
+      AttnArgs a{};
+      a.Q = e->q_d;
+      a.q_bs = (long)n * dt;
+      a.q_rs = dt;
+      a.K = e->kv + (size_t)(2 * li) * dt;
+      a.V = e->kv + (size_t)(2 * li + 1) * dt;
+      a.k_bs = a.v_bs = (long)N_CTX * L * 2 * dt;
+      a.k_rs = a.v_rs = L * 2 * dt;
+      a.O = e->att_d;
+      a.o_bs = (long)n * dt;
+      a.o_rs = dt;
+      a.cap = cap ? cap + (size_t)li * H * n * Fpad : nullptr;
+      a.cap_bs = (long)L * H * n * Fpad;
+      a.cap_hs = (long)n * Fpad;
+      a.cap_ld = Fpad;
+      a.cap_cols = Fcap;
+      a.nq = n;
+      a.nk = N_CTX;
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 0;
+      HIPCHK(launch_attention(a, s));
+    }
+    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2));
+    HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, M, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0));
+    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, M, dt, 4 * dt, 0, 2));
+  }
+  if (logits_out) {
+    HIPCHK(launch_layernorm_f16(e->xd, e->lnf_g, e->lnf_b, e->xdn, M, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, logits_out, D.n_vocab, M, D.n_vocab, dt, 0, 1));
+  }
+  return WCA_OK;
+}
+
+int check_ready(wca_engine* e) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (!e->finalized) return fail(WCA_ERR_STATE, "weights not finalized (call wca_finalize_weights)");
+  HIPCHK(hipSetDevice(e->device));
+  return WCA_OK;
+}
+
+// stage per-utterance metadata into the next device slot: rows = {n_samples, n_tok, n_frames, dtwN}
+int stage_meta(wca_engine* e, int B, const int32_t* a0, const int32_t* a1, const int32_t* a2, const int32_t* a3, int** dev_rows) {
+  const int slot = e->meta_slot;
+  e->meta_slot = (e->meta_slot + 1) % META_SLOTS;
+  int* h = e->meta_host + (size_t)slot * 4 * e->max_batch;
+  int* dv = e->meta_dev + (size_t)slot * 4 * e->max_batch;
+  const int32_t* src[4] = {a0, a1, a2, a3};
+  for (int r = 0; r < 4; ++r)
+    for (int b = 0; b < B; ++b) h[r * e->max_batch + b] = src[r] ? src[r][b] : 0;
+  HIPCHK(hipMemcpyAsync(dv, h, sizeof(int) * 4 * e->max_batch, hipMemcpyHostToDevice, e->stream));
+  for (int r = 0; r < 4; ++r) dev_rows[r] = dv + r * e->max_batch;
+  return WCA_OK;
+}
+
+int run_logmel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int* n_samples_dev, int B, float* mel_out, bool want_tm) {
+  if (!e->have_filters) return fail(WCA_ERR_STATE, "mel_filters not loaded (wca_load_weight(\"mel_filters\"))");
+  LogMelArgs a{};
+  a.pcm = pcm_dev;
+  a.pcm_stride = pcm_stride;
+  a.n_samples = n_samples_dev;
+  a.filters = e->mel_filters;
+  a.filt_lo = e->filt_lo;
+  a.filt_hi = e->filt_hi;
+  a.window = e->window;
+  a.twiddle = e->twiddle;
+  a.mel_out = mel_out;
+  a.mel_tm = want_tm ? e->mel_tm : nullptr;
+  a.n_mels_pad = e->dims.n_mels;
+  a.scratch = e->mel_scratch;
+  a.gmax = e->gmax;
+  a.n_mels = e->dims.n_mels;
+  a.B = B;
+  HIPCHK(launch_logmel(a, e->stream));
+  return WCA_OK;
+}
+
+// mel f32 [B][n_mels][3000] -> time-major f16 image used by the conv GEMM
+__global__ void mel_to_tm_kernel(const float* __restrict__ mel, half_t* __restrict__ tm, int n_mels, int B) {
+  const int b = blockIdx.y;
+  const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e0 >= (long)n_mels * N_FRAMES) return;
+  const int t = (int)(e0 / n_mels), m = (int)(e0 - (long)t * n_mels);
+  tm[((long)b * (N_FRAMES + 2) + t + 1) * n_mels + m] = (half_t)mel[((long)b * n_mels + m) * N_FRAMES + t];
+}
+
+__global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t st = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += st) out[i] = (float)in[i];
+}
+
+int validate_lengths(int B, int n_tok_max, const int32_t* n_tok, const int32_t* max_frames, int* Fmax_out) {
+  if (n_tok_max > MAX_TOK) return fail(WCA_ERR_TOO_LONG, "n_tok %d > %d", n_tok_max, MAX_TOK);
+  if (n_tok_max < 1) return fail(WCA_ERR_INVALID, "n_tok %d < 1", n_tok_max);
+  int Fmax = 0;
+  for (int b = 0; b < B; ++b) {
+    if (n_tok && (n_tok[b] > n_tok_max || n_tok[b] < 0)) return fail(WCA_ERR_INVALID, "n_tok[%d]=%d outside [0,%d]", b, n_tok[b], n_tok_max);
+    if (max_frames[b] > N_CTX) return fail(WCA_ERR_TOO_LONG, "max_frames[%d]=%d > %d", b, max_frames[b], N_CTX);
+    if (max_frames[b] < 1) return fail(WCA_ERR_INVALID, "max_frames[%d]=%d < 1", b, max_frames[b]);
+    Fmax = max_frames[b] > Fmax ? max_frames[b] : Fmax;
+  }
+  *Fmax_out = Fmax;
+  return WCA_OK;
+}
+
+// scores/top-k/aggregate/DTW on a dense weights tensor [B][LH][n_max][Fmax] whose column norms and
+// scores are already in e->colnorm / e->scores.
+int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH, int n_max, int Fmax, const int* n_tok_dev,
+                             const int* n_frames_dev, const int* dtwN_dev, const wca_align_opts* o, int L_layers) {
+  hipStream_t s = e->stream;
+  const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
+  if (o->aggregation == WCA_AGGR_TOPK) {
+    HIPCHK(e->sel.ensure(sizeof(int) * (size_t)B * k));
+    HIPCHK(e->selsc.ensure(sizeof(float) * (size_t)B * k));
+    HIPCHK(launch_topk((const float*)e->scores.p, LH, B, k, (int*)e->sel.p, (float*)e->selsc.p, s));
+  }
+  HIPCHK(e->matrix.ensure(sizeof(float) * (size_t)B * n_max * Fmax));
+  AggregateArgs g{};
+  g.weights = weights;
+  g.w_bs = (long)LH * n_max * Fmax;
+  g.n_tok_max = n_max;
+  g.n_frames_max = Fmax;
+  g.colnorm = (const float*)e->colnorm.p;
+  g.LH = LH;
+  g.B = B;
+  g.n_tok = n_tok_dev;
+  g.n_frames = n_frames_dev;
+  g.row_lo = o->sot_len;
+  g.row_hi_trim = 1;
+  g.matrix = (float*)e->matrix.p;
+  if (o->aggregation == WCA_AGGR_TOPK) {
+    g.sel_idx = (const int*)e->sel.p;
+    g.n_sel = k;
+  } else {
+    g.sel_idx = nullptr;
+    const int H = LH / L_layers;
+    g.head_lo = (L_layers / 2) * H;  // ws[n_layers//2:]  (timing.py:88)
+  }
+  HIPCHK(launch_aggregate(g, s));
+  record(e, 6);
+
+  const int Nmax = n_max - o->sot_len - 1;
+  if (Nmax >= 1) {
+    const int wpr = (Fmax + 15) / 16;
+    const int cap = Nmax + Fmax + 2;
+    HIPCHK(e->trace.ensure(sizeof(uint32_t) * (size_t)B * Nmax * wpr));
+    HIPCHK(e->path.ensure(sizeof(int) * (size_t)B * 2 * cap));
+    HIPCHK(e->pathlen.ensure(sizeof(int) * (size_t)B));
+    HIPCHK(e->jump.ensure(sizeof(int) * (size_t)B * n_max));
+    DtwArgs dg{};
+    dg.matrix = (const float*)e->matrix.p;
+    dg.m_bs = (long)n_max * Fmax;
+    dg.ld = Fmax;
+    dg.N = dtwN_dev;
+    dg.M = n_frames_dev;
+    dg.N_max = Nmax;
+    dg.M_max = Fmax;
+    dg.trace = (uint32_t*)e->trace.p;
+    dg.path = (int*)e->path.p;
+    dg.path_len = (int*)e->pathlen.p;
+    dg.jump_frame = (int*)e->jump.p;
+    dg.P = B;
+    HIPCHK(launch_dtw(dg, s));
+  }
+  return WCA_OK;
+}
+
+int ensure_res_host(wca_engine* e, size_t ints) {
+  if (ints <= e->res_host_ints) return WCA_OK;
+  if (e->res_host) (void)hipHostFree(e->res_host);
+  e->res_host = nullptr;
+  e->res_host_ints = 0;
+  HIPCHK(hipHostMalloc((void**)&e->res_host, ints * sizeof(int), hipHostMallocDefault));
+  e->res_host_ints = ints;
+  return WCA_OK;
+}
+
+}  // namespace
+
+// =================================================================================== C ABI
+extern "C" {
+
+const char* wca_last_error(void) { return g_err.c_str(); }
+int wca_version(void) { return 1; }
+
+int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out) {
+  if (!dims || !out) return fail(WCA_ERR_INVALID, "null argument");
+  if (max_batch < 1 || max_batch > 256) return fail(WCA_ERR_INVALID, "max_batch %d outside [1,256]", max_batch);
+  const wca_model_dims& D = *dims;
+  if (D.n_audio_ctx != N_CTX || D.n_text_ctx != MAX_TOK) return fail(WCA_ERR_INVALID, "n_audio_ctx must be 1500 and n_text_ctx 448");
+  if (D.n_audio_state % 128 || D.n_text_state % 128 || D.n_audio_state / D.n_audio_head != 64 || D.n_text_state / D.n_text_head != 64 ||
+      D.n_audio_state > 1280 || D.n_text_state > 1280)
+    return fail(WCA_ERR_INVALID, "unsupported widths: need n_state %% 128 == 0, n_state <= 1280, head_dim == 64");
+  if (D.n_audio_state != D.n_text_state) return fail(WCA_ERR_INVALID, "n_audio_state != n_text_state");
+  if (D.n_mels % 8 || D.n_mels > 256) return fail(WCA_ERR_INVALID, "n_mels must be a multiple of 8 and <= 256");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (device_ordinal < 0 || device_ordinal >= ndev) return fail(WCA_ERR_INVALID, "device %d not present (%d devices)", device_ordinal, ndev);
+  HIPCHK(hipSetDevice(device_ordinal));
+  wca_engine* e = new wca_engine();
+  e->dims = D;
+  e->device = device_ordinal;
+  e->max_batch = max_batch;
+  HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+  e->wslab_bytes = layout_weights(e, nullptr);
+  HIPCHK(hipMalloc((void**)&e->wslab, e->wslab_bytes));
+  HIPCHK(hipMemset(e->wslab, 0, e->wslab_bytes));
+  layout_weights(e, e->wslab);
+  const size_t abytes = layout_arena(e, nullptr);
+  HIPCHK(hipMalloc((void**)&e->aslab, abytes));
+  HIPCHK(hipMemset(e->aslab, 0, abytes));  // zero pad rows of mel_tm / h1pad and all slack
+  layout_arena(e, e->aslab);
+  HIPCHK(hipHostMalloc((void**)&e->meta_host, sizeof(int) * META_SLOTS * 4 * max_batch, hipHostMallocDefault));
+  for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
+  e->ev_valid = true;
+  // constant tables of the STFT
+  {
+    std::vector<float> win(N_FFT), tw(2 * N_FFT);
+    const double PI = 3.14159265358979323846;
+    for (int n = 0; n < N_FFT; ++n) {
+      win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * PI * n / N_FFT));  // periodic hann
+      tw[2 * n] = (float)std::cos(2.0 * PI * n / N_FFT);
+      tw[2 * n + 1] = (float)std::sin(2.0 * PI * n / N_FFT);
+    }
+    HIPCHK(hipMemcpy(e->window, win.data(), sizeof(float) * N_FFT, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->twiddle, tw.data(), sizeof(float) * 2 * N_FFT, hipMemcpyHostToDevice));
+  }
+  *out = e;
+  return WCA_OK;
+}
+
+void wca_engine_destroy(wca_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (GrowBuf* g : {&e->cap, &e->wws, &e->colnorm, &e->scores, &e->sel, &e->selsc, &e->matrix, &e->trace, &e->path, &e->pathlen,
+                     &e->jump, &e->tmp0, &e->tmp1})
+    g->release();
+  if (e->wslab) (void)hipFree(e->wslab);
+  if (e->aslab) (void)hipFree(e->aslab);
+  if (e->meta_host) (void)hipHostFree(e->meta_host);
+  if (e->res_host) (void)hipHostFree(e->res_host);
+  if (e->ev_valid)
+    for (auto& ev : e->ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+int wca_engine_set_stream(wca_engine* e, void* hip_stream) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  return WCA_OK;
+}
+
+int wca_engine_synchronize(wca_engine* e) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
+int wca_set_profiling(wca_engine* e, int on) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  e->profiling = on != 0;
+  return WCA_OK;
+}
+
+int wca_last_stage_ms(wca_engine* e, float* ms8) {
+  if (!e || !ms8) return fail(WCA_ERR_INVALID, "null argument");
+  if (!e->profiling) return fail(WCA_ERR_STATE, "profiling disabled");
+  HIPCHK(hipEventSynchronize(e->ev[8]));
+  for (int i = 0; i < 7; ++i) HIPCHK(hipEventElapsedTime(&ms8[i], e->ev[i], e->ev[i + 1]));
+  HIPCHK(hipEventElapsedTime(&ms8[7], e->ev[0], e->ev[8]));
+  return WCA_OK;
+}
+
+int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype, const int64_t* shape, int ndim) {
+  if (!e || !name_c || !p || !shape) return fail(WCA_ERR_INVALID, "null argument");
+  if (dtype != WCA_DTYPE_F32 && dtype != WCA_DTYPE_F16) return fail(WCA_ERR_INVALID, "dtype %d", dtype);
+  HIPCHK(hipSetDevice(e->device));
+  const std::string name(name_c);
+  const size_t n = numel(shape, ndim);
+  const wca_model_dims& D = e->dims;
+  const int d = D.n_audio_state, dt = D.n_text_state;
+  int rc = 1;
+#define WANTN(cnt) \
+  if (n != (size_t)(cnt)) return fail(WCA_ERR_INVALID, "weight %s: expected %zu elements, got %zu", name_c, (size_t)(cnt), n)
+  if (name == "mel_filters") {
+    WANTN((size_t)D.n_mels * N_BIN);
+    std::vector<float> f(n);
+    for (size_t i = 0; i < n; ++i) f[i] = host_val(p, dtype, i);
+    std::vector<int> lo(D.n_mels), hi(D.n_mels);
+    for (int m = 0; m < D.n_mels; ++m) {
+      int l = N_BIN, h = 0;
+      for (int k = 0; k < N_BIN; ++k)
+        if (f[(size_t)m * N_BIN + k] != 0.f) {
+          l = k < l ? k : l;
+          h = k + 1;
+        }
+      if (h == 0) l = 0;
+      lo[m] = l;
+      hi[m] = h;
+    }
+    HIPCHK(hipMemcpy(e->mel_filters, f.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->filt_lo, lo.data(), sizeof(int) * D.n_mels, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->filt_hi, hi.data(), sizeof(int) * D.n_mels, hipMemcpyHostToDevice));
+    e->have_filters = true;
+    rc = WCA_OK;
+  } else if (name == "encoder.conv1.weight") {
+    WANTN((size_t)d * D.n_mels * 3);
+    rc = put_conv(e->conv1_w, p, dtype, d, D.n_mels, e->k1pad);
+  } else if (name == "encoder.conv1.bias") {
+    WANTN(d);
+    rc = put_f32(e->conv1_b, p, dtype, n);
+  } else if (name == "encoder.conv2.weight") {
+    WANTN((size_t)d * d * 3);
+    rc = put_conv(e->conv2_w, p, dtype, d, d, 3 * d);
+  } else if (name == "encoder.conv2.bias") {
+    WANTN(d);
+    rc = put_f32(e->conv2_b, p, dtype, n);
+  } else if (name == "encoder.positional_embedding") {
+    WANTN((size_t)N_CTX * d);
+    rc = put_f32(e->enc_pos, p, dtype, n);
+  } else if (name == "encoder.ln_post.weight") {
+    WANTN(d);
+    rc = put_f32(e->lnpost_g, p, dtype, n);
+  } else if (name == "encoder.ln_post.bias") {
+    WANTN(d);
+    rc = put_f32(e->lnpost_b, p, dtype, n);
+  } else if (name == "decoder.token_embedding.weight") {
+    WANTN((size_t)D.n_vocab * dt);
+    rc = put_f16(e->tok_emb, p, dtype, n);
+  } else if (name == "decoder.positional_embedding") {
+    WANTN((size_t)D.n_text_ctx * dt);
+    rc = put_f32(e->dec_pos, p, dtype, n);
+  } else if (name == "decoder.ln.weight") {
+    WANTN(dt);
+    rc = put_f32(e->lnf_g, p, dtype, n);
+  } else if (name == "decoder.ln.bias") {
+    WANTN(dt);
+    rc = put_f32(e->lnf_b, p, dtype, n);
+  } else if (name.rfind("encoder.blocks.", 0) == 0 || name.rfind("decoder.blocks.", 0) == 0) {
+    const bool is_dec = name[0] == 'd';
+    const size_t p0 = 15;
+    const size_t dot = name.find('.', p0);
+    if (dot == std::string::npos) return fail(WCA_ERR_INVALID, "bad weight name %s", name_c);
+    const int li = atoi(name.substr(p0, dot - p0).c_str());
+    const int nl = is_dec ? D.n_text_layer : D.n_audio_layer;
+    if (li < 0 || li >= nl) return fail(WCA_ERR_INVALID, "layer index out of range in %s", name_c);
+    rc = load_block_tensor(e, is_dec ? e->dec[li] : e->enc[li], is_dec, li, name.substr(dot + 1), p, dtype, n, is_dec ? dt : d);
+  }
+#undef WANTN
+  if (rc == WCA_OK) e->loaded.insert(name);
+  return rc < 0 ? rc : WCA_OK;  // unknown names (e.g. alignment_heads) are ignored
+}
+
+int wca_finalize_weights(wca_engine* e) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  const wca_model_dims& D = e->dims;
+  std::vector<std::string> need = {"encoder.conv1.weight", "encoder.conv1.bias", "encoder.conv2.weight", "encoder.conv2.bias",
+                                   "encoder.positional_embedding", "encoder.ln_post.weight", "encoder.ln_post.bias",
+                                   "decoder.token_embedding.weight", "decoder.positional_embedding", "decoder.ln.weight",
+                                   "decoder.ln.bias"};
+  const char* blk[] = {"attn.query.weight", "attn.query.bias", "attn.key.weight", "attn.value.weight", "attn.value.bias",
+                       "attn.out.weight", "attn.out.bias", "attn_ln.weight", "attn_ln.bias", "mlp.0.weight", "mlp.0.bias",
+                       "mlp.2.weight", "mlp.2.bias", "mlp_ln.weight", "mlp_ln.bias"};
+  const char* cblk[] = {"cross_attn.query.weight", "cross_attn.query.bias", "cross_attn.key.weight", "cross_attn.value.weight",
+                        "cross_attn.value.bias", "cross_attn.out.weight", "cross_attn.out.bias", "cross_attn_ln.weight",
+                        "cross_attn_ln.bias"};
+  for (int i = 0; i < D.n_audio_layer; ++i)
+    for (const char* b : blk) need.push_back("encoder.blocks." + std::to_string(i) + "." + b);
+  for (int i = 0; i < D.n_text_layer; ++i) {
+    for (const char* b : blk) need.push_back("decoder.blocks." + std::to_string(i) + "." + b);
+    for (const char* b : cblk) need.push_back("decoder.blocks." + std::to_string(i) + "." + b);
+  }
+  for (const auto& nm : need)
+    if (!e->loaded.count(nm)) return fail(WCA_ERR_STATE, "missing weight %s", nm.c_str());
+  e->finalized = true;
+  return WCA_OK;
+}
+
+int wca_log_mel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host, int batch, float* mel_out_dev) {
+  if (!e || !pcm_dev || !n_samples_host || !mel_out_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  for (int b = 0; b < batch; ++b)
+    if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
+      return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid (pad_or_trim to <= 480000 first)", b, n_samples_host[b]);
+  int* rows[4];
+  int rc = stage_meta(e, batch, n_samples_host, nullptr, nullptr, nullptr, rows);
+  if (rc) return rc;
+  return run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, mel_out_dev, false);
+}
+
+int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* tokens_dev, int batch, int n_tok, const int32_t* n_tok_host,
+                       const int32_t* max_frames_host, int medfilt_width, float qk_scale, float* weights_out_dev,
+                       float* logits_out_dev) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!mel_dev || !tokens_dev || !max_frames_host || !weights_out_dev) return fail(WCA_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  if (medfilt_width < 1 || !(medfilt_width & 1) || medfilt_width > 33) return fail(WCA_ERR_INVALID, "medfilt_width must be odd and <= 33");
+  int Fmax = 0;
+  rc = validate_lengths(batch, n_tok, n_tok_host, max_frames_host, &Fmax);
+  if (rc) return rc;
+  const wca_model_dims& D = e->dims;
+  const int LH = D.n_text_layer * D.n_text_head;
+  const int Fpad = (Fmax + 3) & ~3;
+  std::vector<int32_t> ntok(batch);
+  for (int b = 0; b < batch; ++b) ntok[b] = n_tok_host ? n_tok_host[b] : n_tok;
+  int* rows[4];
+  rc = stage_meta(e, batch, nullptr, ntok.data(), max_frames_host, nullptr, rows);
+  if (rc) return rc;
+  const size_t nel = (size_t)D.n_mels * N_FRAMES;
+  dim3 grid((unsigned)((nel + 255) / 256), batch);
+  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
+  HIPCHK(hipGetLastError());
+  rc = run_encoder(e, batch);
+  if (rc) return rc;
+  rc = run_cross_kv(e, batch);
+  if (rc) return rc;
+  HIPCHK(e->cap.ensure(sizeof(float) * (size_t)batch * LH * n_tok * Fpad));
+  rc = run_decoder(e, tokens_dev, batch, n_tok, (float*)e->cap.p, Fpad, Fmax, logits_out_dev);
+  if (rc) return rc;
+  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)batch * LH * Fmax));
+  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)batch * LH));
+  HeadStatsArgs h{};
+  h.qk = (const float*)e->cap.p;
+  h.qk_bs = (long)LH * n_tok * Fpad;
+  h.qk_hs = (long)n_tok * Fpad;
+  h.qk_ld = Fpad;
+  h.weights = weights_out_dev;
+  h.w_bs = (long)LH * n_tok * Fmax;
+  h.n_tok = rows[1];
+  h.n_frames = rows[2];
+  h.n_tok_max = n_tok;
+  h.n_frames_max = Fmax;
+  h.colnorm = (float*)e->colnorm.p;
+  h.scores = (float*)e->scores.p;
+  h.LH = LH;
+  h.B = batch;
+  h.medfilt_width = medfilt_width;
+  h.qk_scale = qk_scale;
+  h.w_col = 1.f;
+  h.w_row = 1.f;
+  h.w_cov = 0.f;
+  HIPCHK(launch_head_stats(h, e->stream));
+  return WCA_OK;
+}
+
+int wca_median_filter(wca_engine* e, const float* in_dev, float* out_dev, int64_t rows, int F, int width) {
+  if (!e || !in_dev || !out_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (width < 1 || !(width & 1) || width > 33) return fail(WCA_ERR_INVALID, "filter width must be odd and <= 33");
+  HIPCHK(launch_median_filter(in_dev, out_dev, rows, F, width, e->stream));
+  return WCA_OK;
+}
+
+static int stats_on_weights(wca_engine* e, const float* attns_dev, int L, int H, int n, int F, float wc, float wr, float wv, int** rows_out,
+                            int dtwN) {
+  const int LH = L * H;
+  if (L < 1 || H < 1 || n < 1 || n > MAX_TOK) return fail(WCA_ERR_INVALID, "bad shape L=%d H=%d n=%d", L, H, n);
+  if (F < 1 || F > N_CTX) return fail(WCA_ERR_TOO_LONG, "F=%d outside [1,%d]", F, N_CTX);
+  int32_t nt = n, nf = F, dn = dtwN;
+  int rc = stage_meta(e, 1, nullptr, &nt, &nf, &dn, rows_out);
+  if (rc) return rc;
+  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)LH * F));
+  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)LH));
+  HeadStatsArgs h{};
+  h.qk = attns_dev;
+  h.qk_bs = 0;
+  h.qk_hs = (long)n * F;
+  h.qk_ld = F;
+  h.weights = nullptr;
+  h.n_tok = rows_out[1];
+  h.n_frames = rows_out[2];
+  h.n_tok_max = n;
+  h.n_frames_max = F;
+  h.colnorm = (float*)e->colnorm.p;
+  h.scores = (float*)e->scores.p;
+  h.LH = LH;
+  h.B = 1;
+  h.medfilt_width = 1;
+  h.qk_scale = 1.f;
+  h.w_col = wc;
+  h.w_row = wr;
+  h.w_cov = wv;
+  h.input_is_weights = 1;
+  HIPCHK(launch_head_stats(h, e->stream));
+  return WCA_OK;
+}
+
+int wca_filter_attention(wca_engine* e, const float* attns_dev, int L, int H, int n, int F, int topk, float w_colnorm, float w_rownorm,
+                         float w_coverage, float* scores_host, int32_t* sel_idx_host, float* sel_score_host) {
+  if (!e || !attns_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0");
+  int* rows[4];
+  int rc = stats_on_weights(e, attns_dev, L, H, n, F, w_colnorm, w_rownorm, w_coverage, rows, 0);
+  if (rc) return rc;
+  const int LH = L * H;
+  const int keff = topk < LH ? topk : LH;
+  HIPCHK(e->sel.ensure(sizeof(int) * (size_t)topk));
+  HIPCHK(e->selsc.ensure(sizeof(float) * (size_t)topk));
+  HIPCHK(launch_topk((const float*)e->scores.p, LH, 1, topk, (int*)e->sel.p, (float*)e->selsc.p, e->stream));
+  if (scores_host) HIPCHK(hipMemcpyAsync(scores_host, e->scores.p, sizeof(float) * LH, hipMemcpyDeviceToHost, e->stream));
+  if (sel_idx_host) HIPCHK(hipMemcpyAsync(sel_idx_host, e->sel.p, sizeof(int) * keff, hipMemcpyDeviceToHost, e->stream));
+  if (sel_score_host) HIPCHK(hipMemcpyAsync(sel_score_host, e->selsc.p, sizeof(float) * keff, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
+int wca_force_align(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const wca_align_opts* o, float* matrix_host,
+                    int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host, int32_t* sel_idx_host,
+                    float* sel_score_host) {
+  if (!e || !ws_dev || !o || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
+  if (o->aggregation == WCA_AGGR_TOPK && o->topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0 (timing.py:92)");
+  const int N = n - o->sot_len - 1;
+  if (o->sot_len < 0 || N < 1) return fail(WCA_ERR_INVALID, "n=%d leaves no rows after the [sot_len:-1] slice", n);
+  int* rows[4];
+  int rc = stats_on_weights(e, ws_dev, L, H, n, F, o->w_colnorm, o->w_rownorm, o->w_coverage, rows, N);
+  if (rc) return rc;
+  rc = run_select_aggregate_dtw(e, ws_dev, 1, L * H, n, F, rows[1], rows[2], rows[3], o, L);
+  if (rc) return rc;
+  const int cap = N + F + 2;
+  std::vector<int> path(2 * (size_t)cap);
+  int plen = 0;
+  HIPCHK(hipMemcpyAsync(&plen, e->pathlen.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(path.data(), e->path.p, sizeof(int) * 2 * cap, hipMemcpyDeviceToHost, e->stream));
+  if (matrix_host) HIPCHK(hipMemcpyAsync(matrix_host, e->matrix.p, sizeof(float) * (size_t)N * F, hipMemcpyDeviceToHost, e->stream));
+  if (o->aggregation == WCA_AGGR_TOPK) {
+    const int keff = o->topk < L * H ? o->topk : L * H;
+    if (sel_idx_host) HIPCHK(hipMemcpyAsync(sel_idx_host, e->sel.p, sizeof(int) * keff, hipMemcpyDeviceToHost, e->stream));
+    if (sel_score_host) HIPCHK(hipMemcpyAsync(sel_score_host, e->selsc.p, sizeof(float) * keff, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *path_len_host = plen;
+  if (text_idx_host && time_idx_host)
+    for (int i = 0; i < plen; ++i) {
+      text_idx_host[i] = path[cap - plen + i];
+      time_idx_host[i] = path[cap + cap - plen + i];
+    }
+  return WCA_OK;
+}
+
+static int dtw_dev_common(wca_engine* e, const float* matrix_dev, int P, int N, int M, bool want_jump) {
+  if (N < 1 || N > 512 || M < 1 || M > 4096) return fail(WCA_ERR_INVALID, "DTW shape N=%d M=%d unsupported (N<=512, M<=4096)", N, M);
+  const int wpr = (M + 15) / 16, cap = N + M + 2;
+  HIPCHK(e->trace.ensure(sizeof(uint32_t) * (size_t)P * N * wpr));
+  HIPCHK(e->path.ensure(sizeof(int) * (size_t)P * 2 * cap));
+  HIPCHK(e->pathlen.ensure(sizeof(int) * (size_t)P));
+  if (want_jump) HIPCHK(e->jump.ensure(sizeof(int) * (size_t)P * N));
+  DtwArgs dg{};
+  dg.matrix = matrix_dev;
+  dg.m_bs = (long)N * M;
+  dg.ld = M;
+  dg.N_all = N;
+  dg.M_all = M;
+  dg.N_max = N;
+  dg.M_max = M;
+  dg.trace = (uint32_t*)e->trace.p;
+  dg.path = (int*)e->path.p;
+  dg.path_len = (int*)e->pathlen.p;
+  dg.jump_frame = want_jump ? (int*)e->jump.p : nullptr;
+  dg.P = P;
+  HIPCHK(launch_dtw(dg, e->stream));
+  return WCA_OK;
+}
+
+int wca_dtw(wca_engine* e, const float* matrix_host, int N, int M, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host) {
+  if (!e || !matrix_host || !text_idx_host || !time_idx_host || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (N < 1 || M < 1) return fail(WCA_ERR_INVALID, "empty DTW matrix");
+  HIPCHK(e->tmp0.ensure(sizeof(float) * (size_t)N * M));
+  HIPCHK(hipMemcpyAsync(e->tmp0.p, matrix_host, sizeof(float) * (size_t)N * M, hipMemcpyHostToDevice, e->stream));
+  int rc = dtw_dev_common(e, (const float*)e->tmp0.p, 1, N, M, false);
+  if (rc) return rc;
+  const int cap = N + M + 2;
+  std::vector<int> path(2 * (size_t)cap);
+  int plen = 0;
+  HIPCHK(hipMemcpyAsync(&plen, e->pathlen.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(path.data(), e->path.p, sizeof(int) * 2 * cap, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *path_len_host = plen;
+  for (int i = 0; i < plen; ++i) {
+    text_idx_host[i] = path[cap - plen + i];
+    time_idx_host[i] = path[cap + cap - plen + i];
+  }
+  return WCA_OK;
+}
+
+int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int M, int32_t* jump_frame_host) {
+  if (!e || !matrix_dev || !jump_frame_host) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (P < 1) return fail(WCA_ERR_INVALID, "P < 1");
+  int rc = dtw_dev_common(e, matrix_dev, P, N, M, true);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(jump_frame_host, e->jump.p, sizeof(int) * (size_t)P * N, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
+int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
+                            const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host, const int32_t* max_frames_host,
+                            int batch, const wca_align_opts* o) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!pcm_dev || !n_samples_host || !tokens_dev || !n_tok_host || !max_frames_host || !o) return fail(WCA_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
+  if (o->aggregation == WCA_AGGR_TOPK && o->topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0 (timing.py:92)");
+  if (o->medfilt_width < 1 || !(o->medfilt_width & 1) || o->medfilt_width > 33) return fail(WCA_ERR_INVALID, "medfilt_width must be odd and <= 33");
+  int Fmax = 0;
+  rc = validate_lengths(batch, n_tok_max, n_tok_host, max_frames_host, &Fmax);
+  if (rc) return rc;
+  for (int b = 0; b < batch; ++b)
+    if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
+      return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
+  const wca_model_dims& D = e->dims;
+  const int LH = D.n_text_layer * D.n_text_head;
+  const int Fpad = (Fmax + 3) & ~3;
+  std::vector<int32_t> dn(batch);
+  for (int b = 0; b < batch; ++b) {
+    dn[b] = n_tok_host[b] - o->sot_len - 1;
+    if (dn[b] < 0) dn[b] = 0;
+  }
+  int* rows[4];
+  rc = stage_meta(e, batch, n_samples_host, n_tok_host, max_frames_host, dn.data(), rows);
+  if (rc) return rc;
+  record(e, 0);
+  rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
+  if (rc) return rc;
+  record(e, 1);
+  rc = run_encoder(e, batch);
+  if (rc) return rc;
+  record(e, 2);
+  rc = run_cross_kv(e, batch);
+  if (rc) return rc;
+  record(e, 3);
+  HIPCHK(e->cap.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * Fpad));
+  rc = run_decoder(e, tokens_dev, batch, n_tok_max, (float*)e->cap.p, Fpad, Fmax, nullptr);
+  if (rc) return rc;
+  record(e, 4);
+  HIPCHK(e->wws.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * Fmax));
+  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)batch * LH * Fmax));
+  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)batch * LH));
+  HeadStatsArgs h{};
+  h.qk = (const float*)e->cap.p;
+  h.qk_bs = (long)LH * n_tok_max * Fpad;
+  h.qk_hs = (long)n_tok_max * Fpad;
+  h.qk_ld = Fpad;
+  h.weights = (float*)e->wws.p;
+  h.w_bs = (long)LH * n_tok_max * Fmax;
+  h.n_tok = rows[1];
+  h.n_frames = rows[2];
+  h.n_tok_max = n_tok_max;
+  h.n_frames_max = Fmax;
+  h.colnorm = (float*)e->colnorm.p;
+  h.scores = (float*)e->scores.p;
+  h.LH = LH;
+  h.B = batch;
+  h.medfilt_width = o->medfilt_width;
+  h.qk_scale = o->qk_scale;
+  h.w_col = o->w_colnorm;
+  h.w_row = o->w_rownorm;
+  h.w_cov = o->w_coverage;
+  HIPCHK(launch_head_stats(h, e->stream));
+  record(e, 5);
+  rc = run_select_aggregate_dtw(e, (const float*)e->wws.p, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer);
+  if (rc) return rc;
+  record(e, 7);
+  // results -> pinned staging
+  const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
+  rc = ensure_res_host(e, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1));
+  if (rc) return rc;
+  if (n_tok_max - o->sot_len - 1 >= 1)
+    HIPCHK(hipMemcpyAsync(e->res_host, e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, e->stream));
+  if (k > 0)
+    HIPCHK(hipMemcpyAsync(e->res_host + (size_t)batch * n_tok_max, e->sel.p, sizeof(int) * (size_t)batch * k, hipMemcpyDeviceToHost, e->stream));
+  record(e, 8);
+  e->last_batch = batch;
+  e->last_ntok_max = n_tok_max;
+  e->last_topk = k;
+  return WCA_OK;
+}
+
+int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int32_t* jump_frame_host, int32_t* sel_idx_host) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  if (batch != e->last_batch || n_tok_max != e->last_ntok_max) return fail(WCA_ERR_STATE, "fetch does not match the last enqueue");
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (jump_frame_host) memcpy(jump_frame_host, e->res_host, sizeof(int) * (size_t)batch * n_tok_max);
+  if (sel_idx_host && e->last_topk > 0) {
+    if (topk != e->last_topk) return fail(WCA_ERR_STATE, "topk does not match the last enqueue");
+    memcpy(sel_idx_host, e->res_host + (size_t)batch * n_tok_max, sizeof(int) * (size_t)batch * topk);
+  }
+  return WCA_OK;
+}
+
+int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host, const int64_t* tokens_dev,
+                    int n_tok_max, const int32_t* n_tok_host, const int32_t* max_frames_host, int batch, const wca_align_opts* o,
+                    int32_t* jump_frame_host, int32_t* sel_idx_host) {
+  int rc = wca_align_batch_enqueue(e, pcm_dev, pcm_stride, n_samples_host, tokens_dev, n_tok_max, n_tok_host, max_frames_host, batch, o);
+  if (rc) return rc;
+  return wca_align_batch_fetch(e, batch, n_tok_max, o->aggregation == WCA_AGGR_TOPK ? o->topk : 0, jump_frame_host, sel_idx_host);
+}
+
+// ---------------------------------------------------------------- kernel-level test entry points
+int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias, void* c, int M, int N, int K, int gelu, int out_mode) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(gemm(e->stream, (const half_t*)a, K, (const half_t*)w, K, bias, c, N, M, N, K, gelu, out_mode));
+  return WCA_OK;
+}
+
+int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
+                       int B, int H, int nq, int nk, int causal) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  AttnArgs a{};
+  const int d = H * 64;
+  a.Q = (const half_t*)q;
+  a.q_bs = (long)nq * d;
+  a.q_rs = d;
+  a.K = (const half_t*)k;
+  a.k_bs = (long)nk * d;
+  a.k_rs = d;
+  a.V = (const half_t*)v;
+  a.v_bs = (long)nk * d;
+  a.v_rs = d;
+  a.O = (half_t*)o;
+  a.o_bs = (long)nq * d;
+  a.o_rs = d;
+  a.cap = cap_dev;
+  a.cap_bs = (long)H * nq * cap_ld;
+  a.cap_hs = (long)nq * cap_ld;
+  a.cap_ld = cap_ld;
+  a.cap_cols = cap_cols;
+  a.nq = nq;
+  a.nk = nk;
+  a.H = H;
+  a.B = B;
+  a.scale = 0.125f;
+  a.causal = causal;
+  HIPCHK(launch_attention(a, e->stream));
+  return WCA_OK;
+}
+
+int wca_test_layernorm(wca_engine* e, const float* x, const float* g, const float* b, void* out, int rows, int d) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(launch_layernorm_f16(x, g, b, (half_t*)out, rows, d, 1e-5f, e->stream));
+  return WCA_OK;
+}
+
+int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_out_dev) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  const wca_model_dims& D = e->dims;
+  const size_t nel = (size_t)D.n_mels * N_FRAMES;
+  dim3 grid((unsigned)((nel + 255) / 256), batch);
+  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
+  HIPCHK(hipGetLastError());
+  rc = run_encoder(e, batch);
+  if (rc) return rc;
+  // xn holds ln_post(x) in f16; widen for the caller
+  const size_t n = (size_t)batch * N_CTX * D.n_audio_state;
+  hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, n);
+  HIPCHK(hipGetLastError());
+  return WCA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,233 @@
+// f16 x f16 -> f32 MFMA GEMM for gfx950 (MI355X), used for every projection / MLP / conv-stem
+// contraction of the Whisper forward (reference call site: timing.py:58 -> whisper.model Linear/Conv1d).
+//
+//   C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] )
+//
+// Tile 128 x 128 x 64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave),
+// v_mfma_f32_16x16x32_f16, operands staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4)
+// into an XOR-swizzled [row][64] f16 image (swizzle applied on the per-lane SOURCE address, read
+// back with the same XOR), double buffered, one barrier per K tile.
+//
+// The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
+// W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
+// of one output row: the epilogue stores 32 B (f16) / 64 B (f32) per lane per row.
+#include "kernels.h"
+#include "wca_common.h"
+
+namespace wca {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_ELEMS = 128 * 64;  // one operand tile (f16 elements)
+
+struct RowPtrs {
+  const half_t* p[4];
+};
+
+__device__ __forceinline__ half8 ldfrag(const half_t* tile, int r, int c) {
+  return *reinterpret_cast<const half8*>(tile + r * 64 + ((c ^ swz128(r)) << 3));
+}
+
+template <int OUT_MODE, bool GELU>
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+  // layout: [buf][A tile | W tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntn = (a.N + BN - 1) / BN;
+  const int ntm = (a.M + BM - 1) / BM;
+  const int nwg = ntm * ntn;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // Per-lane source rows for the LDS-DMA staging: 4 A rows and 4 W rows, fixed over the K loop.
+  // Wave-instruction i of wave w covers tile rows (w*4+i)*8 .. +7; lane L -> row +(L>>3),
+  // LDS chunk position L&7, which holds global chunk (L&7) ^ swz(row).
+  const half_t* asrc[4];
+  const half_t* wsrc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz128(r);
+    int gm = m0 + r;
+    gm = gm < a.M ? gm : a.M - 1;
+    long aoff;
+    if (a.a_rows_per_batch > 0) {
+      const int b = gm / a.a_rows_per_batch;
+      const int t = gm - b * a.a_rows_per_batch;
+      aoff = (long)b * a.a_batch_stride + (long)t * a.lda;
+    } else {
+      aoff = (long)gm * a.lda;
+    }
+    asrc[i] = a.A + aoff + c * 8;
+    int gn = n0 + r;
+    gn = gn < a.N ? gn : a.N - 1;
+    wsrc[i] = a.W + (long)gn * a.ldw + c * 8;
+  }
+
+  auto stage = [&](int buf, int k0) {
+    half_t* At = lds + buf * (2 * TILE_ELEMS);
+    half_t* Wt = At + TILE_ELEMS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = (wave * 4 + i) * 8;
+      glds16(asrc[i] + k0, At + rbase * 64);
+      glds16(wsrc[i] + k0, Wt + rbase * 64);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15;   // fragment row index
+  const int fg = lane >> 4;   // k-chunk group
+  // activation rows (B operand): natural order; weight rows (A operand): permuted so that
+  // MFMA-row i of n-tile nt is output column (i>>2)*16 + nt*4 + (i&3) of the wave's 64.
+  int xrow[4], wrow[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    xrow[t] = wm * 64 + t * 16 + fr;
+    wrow[t] = wn * 64 + (fr >> 2) * 16 + t * 4 + (fr & 3);
+  }
+
+  const int nk = a.K / BK;
+  stage(0, 0);
+  wait_vm0();
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1, (kt + 1) * BK);
+    const half_t* At = lds + cur * (2 * TILE_ELEMS);
+    const half_t* Wt = At + TILE_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 xf[4], wf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xf[t] = ldfrag(At, xrow[t], ks * 4 + fg);
+        wf[t] = ldfrag(Wt, wrow[t], ks * 4 + fg);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[mt][nt], 0, 0, 0);
+    }
+    wait_vm0();
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane (fr, fg) holds C[m = m0 + wm*64 + mt*16 + fr][n = n0 + wn*64 + fg*16 + nt*4 + r]
+  const int nb = n0 + wn * 64 + fg * 16;
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = (a.bias != nullptr && nb + j < a.N) ? a.bias[nb + j] : 0.f;
+  const bool full_n = (nb + 16 <= a.N);
+
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + fr;
+    if (m >= a.M) continue;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
+    if (GELU) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (a.pos != nullptr) {
+      const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nb;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < a.N) v[j] += pp[j];
+    }
+    long coff;
+    if (a.c_rows_per_batch > 0) {
+      const int b = m / a.c_rows_per_batch;
+      const int t = m - b * a.c_rows_per_batch;
+      coff = (long)b * a.c_batch_stride + (long)t * a.ldc;
+    } else {
+      coff = (long)m * a.ldc;
+    }
+    if (OUT_MODE == 0) {
+      half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
+        half8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h0[j] = (half_t)v[j];
+          h1[j] = (half_t)v[8 + j];
+        }
+        reinterpret_cast<half8*>(cp)[0] = h0;
+        reinterpret_cast<half8*>(cp)[1] = h1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (nb + j < a.N) cp[j] = (half_t)v[j];
+      }
+    } else {
+      float* cp = reinterpret_cast<float*>(a.C) + coff + nb;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
+        f32x4* c4 = reinterpret_cast<f32x4*>(cp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o = f32x4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+          if (OUT_MODE == 2) o += c4[q];
+          c4[q] = o;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (nb + j < a.N) cp[j] = (OUT_MODE == 2) ? cp[j] + v[j] : v[j];
+      }
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0) return hipSuccess;
+  if (a.K <= 0 || (a.K % BK) != 0) return hipErrorInvalidValue;
+  if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
+  const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+  dim3 grid(ntn * ntm), block(256);
+  const size_t shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
+#define WCA_LAUNCH(OM, G)                                                                       \
+  do {                                                                                          \
+    static bool attr_set = false;                                                               \
+    if (!attr_set) {                                                                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<OM, G>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return e;                                                            \
+      attr_set = true;                                                                          \
+    }                                                                                           \
+    hipLaunchKernelGGL((gemm_f16_kernel<OM, G>), grid, block, shmem, s, a);                     \
+  } while (0)
+  if (a.out_mode == 0) {
+    if (a.gelu) WCA_LAUNCH(0, true); else WCA_LAUNCH(0, false);
+  } else if (a.out_mode == 1) {
+    if (a.gelu) WCA_LAUNCH(1, true); else WCA_LAUNCH(1, false);
+  } else if (a.out_mode == 2) {
+    if (a.gelu) return hipErrorInvalidValue;
+    WCA_LAUNCH(2, false);
+  } else {
+    return hipErrorInvalidValue;
+  }
+#undef WCA_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace wca

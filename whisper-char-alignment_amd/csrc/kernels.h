@@ -1,0 +1,130 @@
+// Host-side launch interface of the HIP kernels (internal to libwca.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wca {
+
+typedef _Float16 half_t;
+
+// ---------------------------------------------------------------- GEMM (gemm.hip)
+// C[m][n] = epilogue( sum_k A[m][k] * W[n][k] ),  A/W f16, fp32 accumulate on MFMA.
+// Rows of A and C may be "batch strided": logical row m = b * rows_per_batch + t lives at
+// base + b * batch_stride + t * ld  (this is how the conv stem reads overlapping windows).
+struct GemmArgs {
+  const half_t* A;
+  int lda;                 // elements between consecutive A rows inside a batch
+  int a_rows_per_batch;    // 0 => flat
+  long a_batch_stride;     // elements
+  const half_t* W;         // [N][ldw]
+  int ldw;
+  const float* bias;       // [N] or nullptr
+  void* C;                 // f16 or f32, see `out_mode`
+  int ldc;
+  int c_rows_per_batch;    // 0 => flat
+  long c_batch_stride;     // elements
+  const float* pos;        // optional additive table pos[(m % pos_period)][N] (f32), or nullptr
+  int pos_period;
+  int M, N, K;             // K % 64 == 0
+  int gelu;                // apply exact (erf) GELU after bias
+  int out_mode;            // 0: store f16, 1: store f32, 2: f32 accumulate (C += result)
+};
+hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- attention (attention.hip)
+// Flash-style multi-head attention with head_dim == 64 (every Whisper size).
+// Optionally writes the pre-softmax logits q.k*scale (f32) of the first `cap_cols` keys.
+struct AttnArgs {
+  const half_t* Q; long q_bs; int q_rs;   // element strides: batch, row
+  const half_t* K; long k_bs; int k_rs;
+  const half_t* V; long v_bs; int v_rs;
+  half_t* O; long o_bs; int o_rs;
+  float* cap;                              // nullptr => no capture
+  long cap_bs; long cap_hs; int cap_ld;    // cap[b*cap_bs + h*cap_hs + q*cap_ld + key]
+  int cap_cols;                            // keys [0, cap_cols) are captured (cap_ld % 4 == 0, cap_ld >= roundup4(cap_cols))
+  int nq, nk, H, B;
+  float scale;                             // applied to q.k (head_dim^-0.5)
+  int causal;
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- small ops (elementwise.hip)
+hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out,
+                                int rows, int d, float eps, hipStream_t s);
+// x[b*n + i][:] = tok_emb[tokens[b*n+i]][:] + pos_emb[i][:]
+hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x,
+                        int B, int n, int d, hipStream_t s);
+hipError_t launch_fill_f16(half_t* p, size_t n, float v, hipStream_t s);
+hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
+
+// ---------------------------------------------------------------- log-mel (logmel.hip)
+struct LogMelArgs {
+  const float* pcm;        // [B][pcm_stride] f32 16 kHz, already trimmed/padded by the caller or shorter
+  long pcm_stride;
+  const int* n_samples;    // [B] valid samples per utterance (<= 480000); device pointer
+  const float* filters;    // [n_mels][201]
+  const int* filt_lo;      // [n_mels] first non-zero bin of each filter (device)
+  const int* filt_hi;      // [n_mels] one past the last non-zero bin (device)
+  const float* window;     // [400] periodic hann
+  const float* twiddle;    // [400][2] cos,sin(2*pi*m/400)
+  float* mel_out;          // [B][n_mels][3000] f32 (may be nullptr)
+  half_t* mel_tm;          // [B][3002][n_mels_pad] f16 time-major, rows 0 and 3001 zero (may be nullptr)
+  int n_mels_pad;          // row length of mel_tm
+  float* scratch;          // [B][n_mels][3000] raw log10 values (required)
+  unsigned* gmax;          // [B] ordered-int encoded running max (required)
+  int n_mels, B;
+};
+hipError_t launch_logmel(const LogMelArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- post-processing (postproc.hip)
+struct HeadStatsArgs {
+  const float* qk;         // captured logits: qk[b*qk_bs + head*qk_hs + t*qk_ld + f]
+  long qk_bs; long qk_hs; int qk_ld;
+  float* weights;          // optional dense out: weights[b*w_bs + head*n*F... ] see w_* (nullptr => skip)
+  long w_bs;               // elements between utterances
+  const int* n_tok;        // [B] decoder rows per utterance (device)
+  const int* n_frames;     // [B] F per utterance (device)
+  int n_tok_max, n_frames_max;  // strides of the dense `weights` layout: [head][n_tok_max][n_frames_max]
+  float* colnorm;          // [B][LH][n_frames_max] per-head column L2 norms
+  float* scores;           // [B][LH]
+  int LH, B, medfilt_width;
+  float qk_scale, w_col, w_row, w_cov;
+  int input_is_weights;    // 1: `qk` already holds softmaxed weights (filter_attention on a given tensor): no median/softmax
+};
+hipError_t launch_head_stats(const HeadStatsArgs& a, hipStream_t s);
+
+// ascending top-k (python tuple order: score, then flat head index); k_eff = min(k, LH)
+hipError_t launch_topk(const float* scores, int LH, int B, int k, int* sel_idx /*[B][k]*/,
+                       float* sel_score /*[B][k]*/, hipStream_t s);
+
+struct AggregateArgs {
+  const float* weights; long w_bs; int n_tok_max, n_frames_max;
+  const float* colnorm;    // [B][LH][n_frames_max]
+  const int* sel_idx;      // [B][n_sel] head ids (or nullptr => heads [head_lo, LH))
+  int n_sel, head_lo, LH, B;
+  const int* n_tok; const int* n_frames;
+  int row_lo, row_hi_trim; // output rows [row_lo, n_tok - row_hi_trim)
+  float* matrix;           // [B][n_tok_max][n_frames_max]
+};
+hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s);
+
+// standalone median filter along the last axis with reflect padding (whisper.timing.median_filter)
+hipError_t launch_median_filter(const float* in, float* out, long rows, int F, int width, hipStream_t s);
+
+// ---------------------------------------------------------------- DTW (dtw.hip)
+struct DtwArgs {
+  const float* matrix;     // P problems: matrix + p*m_bs, rows ld apart; DTW runs on the NEGATED matrix
+  long m_bs; int ld;
+  const int* N;            // [P] rows per problem (device)   (or nullptr => N_all)
+  const int* M;            // [P] cols per problem (device)   (or nullptr => M_all)
+  int N_all, M_all;
+  int N_max, M_max;
+  uint32_t* trace;         // workspace: P * N_max * ceil(M_max/16) words
+  int* path;               // [P][2][cap] text idx row then time idx row, right-aligned; cap = N_max + M_max + 2
+  int* path_len;           // [P]
+  int* jump_frame;         // [P][N_max] first frame of each text row (or nullptr)
+  int P;
+};
+hipError_t launch_dtw(const DtwArgs& a, hipStream_t s);
+
+}  // namespace wca

@@ -1,0 +1,327 @@
+// Post-processing of the captured cross-attention logits on gfx950 (all HBM-bound, no MFMA):
+//   head_stats : median filter (reflect pad) -> *qk_scale -> softmax over frames      timing.py:64-66
+//                + per-head score  w_col*sum_f||A[:,f]|| + w_row*sum_t||A[t,:]|| - w_cov*coverage   timing.py:13-34, metrics.py:99-111
+//                in ONE pass over the logits (one workgroup per head, one wave per token row).
+//   topk       : ascending top-k heads in python tuple order (score, (l,h))            timing.py:36
+//   aggregate  : mean over selected heads of A / ||A||_col                              timing.py:84-97
+//   median_filter : standalone whisper.timing.median_filter
+#include "kernels.h"
+#include "wca_common.h"
+
+namespace wca {
+
+namespace {
+
+constexpr int MAX_NPL = 24;   // values per lane: frames <= 64 * 24 = 1536 >= 1500
+constexpr int HALO = 16;      // supports filter widths up to 33
+
+__device__ __forceinline__ void cswap(float& a, float& b) {
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+
+// median of W values starting at p (LDS), W odd, compile time
+template <int W>
+__device__ __forceinline__ float median_w(const float* p) {
+  if (W == 1) return p[0];
+  float v[W];
+#pragma unroll
+  for (int i = 0; i < W; ++i) v[i] = p[i];
+  // odd-even transposition sort, W passes (branch free)
+#pragma unroll
+  for (int pass = 0; pass < W; ++pass) {
+#pragma unroll
+    for (int i = (pass & 1); i + 1 < W; i += 2) cswap(v[i], v[i + 1]);
+  }
+  return v[W / 2];
+}
+
+// generic odd width: rank selection by counting (ties broken by index) == sorted[w/2]
+__device__ __forceinline__ float median_generic(const float* p, int w) {
+  const int target = w >> 1;
+  float res = p[0];
+  for (int i = 0; i < w; ++i) {
+    const float vi = p[i];
+    int rank = 0;
+    for (int j = 0; j < w; ++j) {
+      const float vj = p[j];
+      rank += (vj < vi) || (vj == vi && j < i);
+    }
+    if (rank == target) res = vi;
+  }
+  return res;
+}
+
+__device__ __forceinline__ float median_any(const float* p, int w) {
+  switch (w) {
+    case 1: return p[0];
+    case 3: return median_w<3>(p);
+    case 5: return median_w<5>(p);
+    case 7: return median_w<7>(p);
+    case 9: return median_w<9>(p);
+    default: return median_generic(p, w);
+  }
+}
+
+// Fill rowbuf[HALO + f] (f in [0,F)) from a global row, plus reflect halos of `pad` on both sides.
+__device__ __forceinline__ void load_row_reflect(const float* __restrict__ src, float* rowbuf, int F, int pad, int lane) {
+  for (int f = lane; f < F; f += 64) rowbuf[HALO + f] = src[f];
+  __builtin_amdgcn_wave_barrier();
+  if (lane < pad) {
+    const int k = lane + 1;                       // 1..pad
+    rowbuf[HALO - k] = rowbuf[HALO + k];           // x[-k] = x[k]
+    rowbuf[HALO + F - 1 + k] = rowbuf[HALO + F - 1 - k];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NPL>
+__global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);
+  const int Fmax = a.n_frames_max;
+  const int rb_stride = Fmax + 2 * HALO;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* rowbuf = sm + wave * rb_stride;
+  float* red_sq = sm + 4 * rb_stride;            // [4][Fmax]
+  float* red_sum = red_sq + 4 * Fmax;            // [4][Fmax]
+  float* red_scalar = red_sum + 4 * Fmax;        // [16]
+
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int n = a.n_tok[b], F = a.n_frames[b];
+  const int w = a.medfilt_width;
+  const int pad = w >> 1;
+  const bool do_med = (w > 1) && (F > pad) && !a.input_is_weights;
+  const float* qk = a.qk + (long)b * a.qk_bs + (long)head * a.qk_hs;
+  float* wout = a.weights ? a.weights + (long)b * a.w_bs + (long)head * a.n_tok_max * Fmax : nullptr;
+
+  float csq[NPL], csum[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    csq[i] = 0.f;
+    csum[i] = 0.f;
+  }
+  float rown_acc = 0.f;
+
+  for (int t = wave; t < n; t += 4) {
+    const float* src = qk + (long)t * a.qk_ld;
+    float v[NPL];
+    if (do_med) {
+      load_row_reflect(src, rowbuf, F, pad, lane);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        v[i] = (f < F) ? median_any(rowbuf + HALO + f - pad, w) : -INFINITY;
+      }
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        v[i] = (f < F) ? src[f] : -INFINITY;
+      }
+    }
+    float sum = 1.0f;
+    if (!a.input_is_weights) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        v[i] = (f < F) ? v[i] * a.qk_scale : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+      }
+      mx = wave_max(mx);
+      sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        v[i] = (f < F) ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+      }
+      sum = wave_sum(sum);
+    }
+    float rsq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+      const int f = lane + 64 * i;
+      const float p = a.input_is_weights ? v[i] : v[i] / sum;
+      if (f < F) {
+        if (wout) wout[(long)t * Fmax + f] = p;
+        rsq += p * p;
+        csq[i] += p * p;
+        csum[i] += p;
+      }
+    }
+    rown_acc += sqrtf(wave_sum(rsq));
+  }
+
+  // ---- deterministic cross-wave reduction of the per-column statistics
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = lane + 64 * i;
+    if (f < F) {
+      red_sq[wave * Fmax + f] = csq[i];
+      red_sum[wave * Fmax + f] = csum[i];
+    }
+  }
+  if (lane == 0) red_scalar[wave] = rown_acc;
+  __syncthreads();
+  float cn_part = 0.f, cov_part = 0.f;
+  float* cn_out = a.colnorm + ((long)b * a.LH + head) * Fmax;
+  for (int f = tid; f < F; f += 256) {
+    const float sq = ((red_sq[f] + red_sq[Fmax + f]) + red_sq[2 * Fmax + f]) + red_sq[3 * Fmax + f];
+    const float sm_ = ((red_sum[f] + red_sum[Fmax + f]) + red_sum[2 * Fmax + f]) + red_sum[3 * Fmax + f];
+    const float cn = sqrtf(sq);
+    cn_out[f] = cn;
+    cn_part += cn;
+    cov_part += fmaxf(sm_, 0.5f);
+  }
+  cn_part = wave_sum(cn_part);
+  cov_part = wave_sum(cov_part);
+  if (lane == 0) {
+    red_scalar[4 + wave] = cn_part;
+    red_scalar[8 + wave] = cov_part;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float rown = ((red_scalar[0] + red_scalar[1]) + red_scalar[2]) + red_scalar[3];
+    const float coln = ((red_scalar[4] + red_scalar[5]) + red_scalar[6]) + red_scalar[7];
+    const float cov = (((red_scalar[8] + red_scalar[9]) + red_scalar[10]) + red_scalar[11]) - 0.5f * (float)F;
+    float score = 0.f;
+    if (a.w_col > 0.f) score += a.w_col * coln;
+    if (a.w_row > 0.f) score += a.w_row * rown;
+    if (a.w_cov > 0.f) score -= a.w_cov * cov;
+    a.scores[(long)b * a.LH + head] = score;
+  }
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ scores, int LH, int k, int* __restrict__ sel_idx,
+                                                   float* __restrict__ sel_score) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sc = reinterpret_cast<float*>(smem);
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < LH; i += blockDim.x) sc[i] = scores[(long)b * LH + i];
+  __syncthreads();
+  const int keff = k < LH ? k : LH;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    if (i >= keff) {
+      sel_idx[(long)b * k + i] = -1;
+      sel_score[(long)b * k + i] = 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < LH; i += blockDim.x) {
+    const float si = sc[i];
+    int rank = 0;  // number of heads that sort AFTER head i in ascending (score, index) order
+    for (int j = 0; j < LH; ++j) {
+      const float sj = sc[j];
+      rank += (sj > si) || (sj == si && j > i);
+    }
+    if (rank < keff) {
+      sel_idx[(long)b * k + (keff - 1 - rank)] = i;
+      sel_score[(long)b * k + (keff - 1 - rank)] = si;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
+  const int b = blockIdx.z;
+  const int n = a.n_tok[b], F = a.n_frames[b];
+  const int t = a.row_lo + blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n - a.row_hi_trim || f >= F) return;
+  const int Fmax = a.n_frames_max;
+  const float* W = a.weights + (long)b * a.w_bs;
+  const float* CN = a.colnorm + (long)b * a.LH * Fmax;
+  float acc = 0.f;
+  int cnt;
+  if (a.sel_idx) {
+    cnt = 0;
+    for (int s = 0; s < a.n_sel; ++s) {
+      const int hd = a.sel_idx[(long)b * a.n_sel + s];
+      if (hd < 0) continue;
+      acc += W[((long)hd * a.n_tok_max + t) * Fmax + f] / CN[(long)hd * Fmax + f];
+      ++cnt;
+    }
+  } else {
+    cnt = a.LH - a.head_lo;
+    for (int hd = a.head_lo; hd < a.LH; ++hd)
+      acc += W[((long)hd * a.n_tok_max + t) * Fmax + f] / CN[(long)hd * Fmax + f];
+  }
+  a.matrix[((long)b * a.n_tok_max + (t - a.row_lo)) * Fmax + f] = acc / (float)cnt;
+}
+
+__global__ __launch_bounds__(256) void median_filter_kernel(const float* __restrict__ in, float* __restrict__ out, long rows,
+                                                            int F, int w) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* rowbuf = sm + wave * (F + 2 * HALO);
+  const int pad = w >> 1;
+  for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+    const float* src = in + row * F;
+    float* dst = out + row * F;
+    if (w <= 1 || F <= pad) {
+      for (int f = lane; f < F; f += 64) dst[f] = src[f];
+      continue;
+    }
+    load_row_reflect(src, rowbuf, F, pad, lane);
+    for (int f = lane; f < F; f += 64) dst[f] = median_any(rowbuf + HALO + f - pad, w);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace
+
+hipError_t launch_head_stats(const HeadStatsArgs& a, hipStream_t s) {
+  if (a.B <= 0 || a.LH <= 0) return hipSuccess;
+  if (a.n_frames_max <= 0 || a.n_frames_max > 64 * MAX_NPL) return hipErrorInvalidValue;
+  if (a.medfilt_width < 1 || (a.medfilt_width & 1) == 0 || (a.medfilt_width >> 1) > HALO) return hipErrorInvalidValue;
+  const int Fmax = a.n_frames_max;
+  const size_t shmem = sizeof(float) * (4 * (size_t)(Fmax + 2 * HALO) + 8 * (size_t)Fmax + 16);
+  dim3 grid(a.LH, a.B), block(256);
+#define WCA_HS(NPL)                                                                                \
+  do {                                                                                             \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_stats_kernel<NPL>),      \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);    \
+    if (e != hipSuccess) return e;                                                                 \
+    hipLaunchKernelGGL((head_stats_kernel<NPL>), grid, block, shmem, s, a);                        \
+  } while (0)
+  if (Fmax <= 64 * 8) WCA_HS(8);
+  else if (Fmax <= 64 * 16) WCA_HS(16);
+  else WCA_HS(24);
+#undef WCA_HS
+  return hipGetLastError();
+}
+
+hipError_t launch_topk(const float* scores, int LH, int B, int k, int* sel_idx, float* sel_score, hipStream_t s) {
+  if (B <= 0 || k <= 0) return hipSuccess;
+  if (LH <= 0 || LH > 8192) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), sizeof(float) * LH, s, scores, LH, k, sel_idx, sel_score);
+  return hipGetLastError();
+}
+
+hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s) {
+  if (a.B <= 0) return hipSuccess;
+  const int rows = a.n_tok_max - a.row_lo - a.row_hi_trim;
+  if (rows <= 0) return hipSuccess;
+  dim3 grid((a.n_frames_max + 255) / 256, rows, a.B), block(256);
+  hipLaunchKernelGGL(aggregate_kernel, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_median_filter(const float* in, float* out, long rows, int F, int width, hipStream_t s) {
+  if (rows <= 0 || F <= 0) return hipSuccess;
+  if (width < 1 || (width & 1) == 0 || (width >> 1) > HALO) return hipErrorInvalidValue;
+  const size_t shmem = sizeof(float) * 4 * (size_t)(F + 2 * HALO);
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;
+  long blocks = (rows + 3) / 4;
+  if (blocks > 8192) blocks = 8192;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(median_filter_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(median_filter_kernel, dim3((unsigned)blocks), dim3(256), shmem, s, in, out, rows, F, width);
+  return hipGetLastError();
+}
+
+}  // namespace wca

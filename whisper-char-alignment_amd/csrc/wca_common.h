@@ -1,0 +1,59 @@
+// Shared device/host helpers for the MI355X (gfx950) forced-alignment engine.
+// Everything here is written for CDNA4 only: 64-wide wavefronts, MFMA, LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace wca {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2_ __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+
+#define WCA_LDS __attribute__((address_space(3)))
+#define WCA_GLOBAL __attribute__((address_space(1)))
+
+constexpr int kWave = 64;
+
+// ---- LDS-DMA: 16 bytes per lane, LDS destination = wave-uniform base + lane*16 ----
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const WCA_GLOBAL void*)gsrc, (WCA_LDS void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Swizzle for [rows][64 x f16] (128-byte rows) LDS tiles read with ds_read_b128:
+// 16-byte chunk c of row r lives at chunk position c ^ swz(r). Conflict-free for the
+// MFMA operand reads used in gemm.hip / attention.hip (checked against the gfx950
+// ds_read_b128 lane groups).
+__device__ __forceinline__ int swz128(int r) { return ((r >> 1) ^ (r >> 3)) & 7; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: blocks that share an XCD
+// (id % 8 equal) get a contiguous range of logical ids, so neighbouring tiles hit one L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = orig & 7, idx = orig >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace wca

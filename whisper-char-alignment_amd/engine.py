@@ -1,0 +1,226 @@
+"""Model handle of the MI355X engine: the object callers pass as `model` to timing.get_attentions
+(reference: `whisper.load_model(...)` at infer_ali.py:36 / README.md:93).
+
+It exposes the attributes the reference's callers touch (`model.device`, `model.dims.n_text_layer`,
+`model.is_multilingual`; infer_ali.py:41,46, timing.py:48) and owns one `wca_engine` (weights in HBM as
+f16, activation arena, HIP stream). PyTorch-ROCm is used only to hold device buffers and to read
+checkpoints; all arithmetic happens in libwca.so.
+"""
+import ctypes as C
+from dataclasses import dataclass, asdict
+
+import numpy as np
+import torch
+
+from . import _lib
+from .audio import mel_filters
+
+N_FRAMES = 3000
+N_SAMPLES = 480000
+MAX_FRAMES = 1500   # infer_ali.py:25
+MAX_LENGTH = 448    # infer_ali.py:26
+
+
+@dataclass
+class ModelDimensions:
+    """Same fields as whisper.model.ModelDimensions."""
+    n_mels: int
+    n_audio_ctx: int
+    n_audio_state: int
+    n_audio_head: int
+    n_audio_layer: int
+    n_vocab: int
+    n_text_ctx: int
+    n_text_state: int
+    n_text_head: int
+    n_text_layer: int
+
+
+# whisper model sizes
+_SIZES = {
+    "tiny": (384, 6, 4), "base": (512, 8, 6), "small": (768, 12, 12), "medium": (1024, 16, 24),
+    "large": (1280, 20, 32), "large-v1": (1280, 20, 32), "large-v2": (1280, 20, 32), "large-v3": (1280, 20, 32),
+}
+
+
+def dims_for(name):
+    """ModelDimensions for an official model name ('medium', 'tiny.en', 'large-v3', ...)."""
+    base = name[:-3] if name.endswith(".en") else name
+    if base not in _SIZES:
+        raise ValueError("unknown whisper model %r" % name)
+    d, h, l = _SIZES[base]
+    multilingual = not name.endswith(".en")
+    n_mels = 128 if base == "large-v3" else 80
+    n_vocab = 51866 if base == "large-v3" else (51865 if multilingual else 51864)
+    return ModelDimensions(n_mels, 1500, d, h, l, n_vocab, 448, d, h, l)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class WhisperAMD:
+    def __init__(self, dims, device="cuda:0", max_batch=8):
+        if not torch.cuda.is_available():
+            raise RuntimeError("WhisperAMD needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self._lib = _lib.load()
+        self.dims = dims
+        self.device = torch.device(device)
+        self.max_batch = int(max_batch)
+        self._h = C.c_void_p(0)
+        cd = _lib.ModelDims(**asdict(dims))
+        index = self.device.index if self.device.index is not None else 0
+        _lib.check(self._lib.wca_engine_create(C.byref(cd), index, self.max_batch, C.byref(self._h)))
+        self._stream_bound = None
+        self._finalized = False
+        filt = np.ascontiguousarray(mel_filters(dims.n_mels), dtype=np.float32)
+        self._load_one("mel_filters", filt)
+
+    # ---- whisper.model.Whisper-like attributes
+    @property
+    def is_multilingual(self):
+        return self.dims.n_vocab >= 51865
+
+    @property
+    def num_languages(self):
+        return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise ValueError("a WhisperAMD engine is bound to %s at construction" % self.device)
+        return self
+
+    def eval(self):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                self._lib.wca_engine_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+    # ---- weights
+    def _load_one(self, name, arr):
+        if isinstance(arr, torch.Tensor):
+            arr = arr.detach().cpu()
+            if arr.dtype == torch.float16:
+                arr = arr.contiguous().numpy()
+            else:
+                arr = arr.float().contiguous().numpy()
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype == np.float16:
+            dt = _lib.DTYPE_F16
+        else:
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            dt = _lib.DTYPE_F32
+        shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
+        _lib.check(self._lib.wca_load_weight(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), dt, shape, max(arr.ndim, 1)))
+
+    def load_state_dict(self, sd):
+        """sd: openai-whisper naming (encoder.blocks.0.attn.query.weight ...), torch tensors or numpy arrays."""
+        for name, t in sd.items():
+            self._load_one(name, t)
+        _lib.check(self._lib.wca_finalize_weights(self._h))
+        self._finalized = True
+        return self
+
+    @classmethod
+    def from_checkpoint(cls, path, device="cuda:0", max_batch=8):
+        """Loads an openai-format checkpoint ({'dims':..., 'model_state_dict':...}) from a LOCAL path."""
+        ck = torch.load(path, map_location="cpu")
+        dims = ModelDimensions(**ck["dims"])
+        m = cls(dims, device=device, max_batch=max_batch)
+        return m.load_state_dict(ck["model_state_dict"])
+
+    # ---- stream handling: always run on torch's current stream so torch tensors stay ordered
+    def _bind_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._stream_bound:
+            _lib.check(self._lib.wca_engine_set_stream(self._h, C.c_void_p(s)))
+            self._stream_bound = s
+
+    def synchronize(self):
+        _lib.check(self._lib.wca_engine_synchronize(self._h))
+
+    # ---- hot path entry points (thin wrappers; shapes documented in include/wca.h)
+    def log_mel(self, pcm, n_samples=None):
+        """pcm: f32 cuda tensor [n] or [B, n] (n <= 480000). Returns [n_mels, 3000] or [B, n_mels, 3000]."""
+        single = pcm.dim() == 1
+        p = pcm[None] if single else pcm
+        p = p.to(self.device, torch.float32).contiguous()
+        B, n = p.shape
+        if n > N_SAMPLES:
+            p = p[:, :N_SAMPLES].contiguous()
+            n = N_SAMPLES
+        ns = [n] * B if n_samples is None else [min(int(v), n) for v in n_samples]
+        out = torch.empty(B, self.dims.n_mels, N_FRAMES, device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        for b0 in range(0, B, self.max_batch):
+            b1 = min(B, b0 + self.max_batch)
+            _lib.check(self._lib.wca_log_mel(self._h, _ptr(p[b0:b1]), n, _lib.i32_array(ns[b0:b1]), b1 - b0, _ptr(out[b0:b1])))
+        return out[0] if single else out
+
+    def get_attentions(self, mel, tokens, max_frames, medfilt_width=7, qk_scale=1.0, n_tok=None, want_logits=True):
+        """mel [B,n_mels,3000] f32, tokens [B,n] int64, max_frames list[int] -> (weights [B,L,H,n,F], logits [B,n,V])."""
+        mel = mel.to(self.device, torch.float32).contiguous()
+        tokens = tokens.to(self.device, torch.int64).contiguous()
+        B, n = tokens.shape
+        if B > self.max_batch:
+            raise ValueError("batch %d > engine max_batch %d" % (B, self.max_batch))
+        mf = [int(v) for v in max_frames]
+        F = max(mf)
+        L, H = self.dims.n_text_layer, self.dims.n_text_head
+        weights = torch.empty(B, L, H, n, max(F, 1), device=self.device, dtype=torch.float32)
+        logits = torch.empty(B, n, self.dims.n_vocab, device=self.device, dtype=torch.float32) if want_logits else None
+        self._bind_stream()
+        nt = _lib.i32_array(n_tok) if n_tok is not None else None
+        _lib.check(self._lib.wca_get_attentions(self._h, _ptr(mel), _ptr(tokens), B, n, nt, _lib.i32_array(mf),
+                                                int(medfilt_width), float(qk_scale), _ptr(weights), _ptr(logits)))
+        return weights, logits
+
+    def encode(self, mel):
+        """Encoder only (tests): mel [B,n_mels,3000] -> ln_post output [B,1500,d] f32."""
+        mel = mel.to(self.device, torch.float32).contiguous()
+        B = mel.shape[0]
+        out = torch.empty(B, 1500, self.dims.n_audio_state, device=self.device, dtype=torch.float32)
+        self._bind_stream()
+        _lib.check(self._lib.wca_test_encoder(self._h, _ptr(mel), B, _ptr(out)))
+        return out
+
+    def make_opts(self, aggregation="mean", topk=-1, w_colnorm=1.0, w_rownorm=1.0, w_coverage=0.0, sot_len=3,
+                  medfilt_width=7, qk_scale=1.0):
+        if aggregation not in ("mean", "topk"):
+            raise ValueError("aggregation must be 'mean' or 'topk'")
+        if aggregation == "topk":
+            assert topk > 0  # timing.py:92
+        return _lib.AlignOpts(_lib.AGGR_TOPK if aggregation == "topk" else _lib.AGGR_MEAN, int(topk), float(w_colnorm),
+                              float(w_rownorm), float(w_coverage), int(sot_len), int(medfilt_width), float(qk_scale))
+
+    def align_batch(self, pcm, n_samples, tokens, n_tok, max_frames, opts, enqueue_only=False):
+        """Fused pipeline. pcm [B,stride] f32 cuda, tokens [B,n_max] int64 cuda. Returns (jump_frames [B,n_max] int32, sel [B,topk])."""
+        B, n_max = tokens.shape
+        self._bind_stream()
+        args = (self._h, _ptr(pcm), pcm.shape[1], _lib.i32_array(n_samples), _ptr(tokens), n_max, _lib.i32_array(n_tok),
+                _lib.i32_array(max_frames), B, C.byref(opts))
+        _lib.check(self._lib.wca_align_batch_enqueue(*args))
+        if enqueue_only:
+            return None
+        return self.fetch(B, n_max, opts)
+
+    def fetch(self, B, n_max, opts):
+        k = opts.topk if opts.aggregation == _lib.AGGR_TOPK else 0
+        jump = np.zeros((B, n_max), dtype=np.int32)
+        sel = np.zeros((B, max(k, 1)), dtype=np.int32)
+        _lib.check(self._lib.wca_align_batch_fetch(self._h, B, n_max, k, jump.ctypes.data_as(_lib._pi32),
+                                                   sel.ctypes.data_as(_lib._pi32)))
+        return jump, (sel if k > 0 else None)
+
+    def set_profiling(self, on):
+        _lib.check(self._lib.wca_set_profiling(self._h, 1 if on else 0))
+
+    def last_stage_ms(self):
+        ms = (C.c_float * 8)()
+        _lib.check(self._lib.wca_last_stage_ms(self._h, ms))
+        return list(ms)
