@@ -86,7 +86,8 @@ int wca_version(void);
 /* ---- engine lifetime ------------------------------------------------------------------------ */
 int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out);
 void wca_engine_destroy(wca_engine* e);
-/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = engine-owned stream */
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the HIP default (null)
+ * stream. Until this is called the engine runs on a private non-blocking stream of its own. */
 int wca_engine_set_stream(wca_engine* e, void* hip_stream);
 int wca_engine_synchronize(wca_engine* e);
 
@@ -173,6 +174,10 @@ int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_o
  * engine stream: [0] log-mel, [1] encoder, [2] cross K/V projection, [3] decoder, [4] head stats,
  * [5] top-k + aggregate, [6] DTW, [7] total. Valid after a synchronize/fetch. */
 int wca_last_stage_ms(wca_engine* e, float* ms8);
+/* Dominant kernel (encoder MLP fc1 GEMM, gemm_f16_kernel<0,true,1>): number of launches in the last
+ * wca_align_batch* call, their summed HIP-event duration and the algorithmic FLOPs of one launch
+ * (2 * batch*1500 * 4d * d). Needs profiling enabled. */
+int wca_last_dominant_kernel_ms(wca_engine* e, int* n_launches, float* total_ms, double* flops_per_launch);
 /* enable/disable per-stage event recording (default off: no extra events on the stream) */
 int wca_set_profiling(wca_engine* e, int on);
 

@@ -1,0 +1,131 @@
+"""End-to-end parity on the MI355X (`-m gpu`): the engine's forward (encoder, decoder with captured
+cross-attention logits, post-processing, DTW) against the CPU oracle on seeded tiny-dims models, and the
+fused wca_align_batch path against the step-by-step drop-in API."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    m = lambda n: importlib.import_module("whisper-char-alignment_amd." + n)  # noqa: E731
+    return m("synthetic"), m("tokenizer"), m("retokenize"), m("timing"), m("audio")
+
+
+@pytest.fixture(scope="module")
+def setup(wca):
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
+    sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    tok = tk.get_tokenizer(True, language="English")
+    return dims, sd, model, tok
+
+
+def _utt(syn, rt, tok, uid, n_samples, n_chars):
+    pcm = syn.synth_audio(uid, n_samples)
+    text = syn.synth_text(uid, n_chars)
+    tt = rt.encode(text, tok, "char")
+    tokens = [*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]
+    return pcm, text, tt, tokens
+
+
+def test_encoder_vs_oracle(wca, setup):
+    from oracle import whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pcm = np.stack([syn.synth_audio(u, 48000) for u in range(2)])
+    mel = model.log_mel(torch.from_numpy(pcm).cuda())
+    got = model.encode(mel).cpu()
+    ref = whisper_ref.WhisperRef(sd, dims).encoder(mel.cpu())
+    # f16 GEMM operands / f16 attention probabilities vs fp32: LayerNorm-ed outputs are O(1)
+    err = (got - ref).abs()
+    assert err.max().item() < 3e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+
+
+@pytest.mark.parametrize("medfilt,secs,chars", [(3, 3.0, 20), (7, 5.0, 40), (1, 2.0, 9)])
+def test_get_attentions_vs_oracle(wca, setup, medfilt, secs, chars):
+    from oracle import timing_ref, whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 7, int(secs * 16000), chars)
+    max_frames = len(pcm) // 320
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    w, logits = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, max_frames, medfilt_width=medfilt)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    rw, rlogits = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, max_frames, medfilt, 1.0)
+    assert tuple(w.shape) == tuple(rw.shape) == (dims.n_text_layer, dims.n_text_head, len(tokens), max_frames)
+    # softmaxed maps (values in [0,1]); f16 operand rounding in the forward
+    assert (w.cpu() - rw).abs().max().item() < 5e-3
+    # logits: O(1) values through 3 decoder layers
+    assert (logits.cpu() - rlogits).abs().max().item() < 5e-2
+    # rows sum to one
+    assert torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-5)
+
+
+def test_force_align_word_times_within_one_frame(wca, setup):
+    """north_star tolerance: word start/end within one 20 ms frame of the CPU reference path."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    ref = whisper_ref.WhisperRef(sd, dims)
+    rtok = tokenizer_ref.CharTokenizer()
+    n_words = n_close = 0
+    for uid in range(4):
+        pcm, text, tt, tokens = _utt(syn, rt, tok, 20 + uid, 64000, 30)
+        max_frames = len(pcm) // 320
+        mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+        w, _ = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, max_frames, medfilt_width=3)
+        words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=4)
+        rw, _ = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, max_frames, 3, 1.0)
+        rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 4)
+        assert words == rwords
+        # given the SAME matrix the GPU DTW is bit-exact
+        ti, tj = timing_ref.dtw(-matrix)
+        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+        wb = np.pad(np.cumsum([len(t) for t in rt.split_tokens_on_spaces(tt + [tok.eot], tok, "char")[1][:-1]]), (1, 0))
+        assert np.array_equal(st, (tj[jumps] / 50)[wb[:-1]]) and np.array_equal(en, (tj[jumps] / 50)[wb[1:]])
+        n_words += 2 * len(st)
+        n_close += int((np.abs(st - rst) <= 0.0201).sum() + (np.abs(en - ren) <= 0.0201).sum())
+    # end to end (f16 forward vs fp32 CPU forward): boundaries within one frame
+    assert n_close >= 0.9 * n_words, (n_close, n_words)
+
+
+def test_align_batch_matches_stepwise_api(wca, setup):
+    """The fused micro-batch path (ragged lengths) must give the same jump frames as the drop-in
+    get_attentions + force_align calls, utterance by utterance."""
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    specs = [(31, 48000, 25), (32, 80000, 40), (33, 32000, 12)]
+    utts = [_utt(syn, rt, tok, u, n, c) for u, n, c in specs]
+    n_max = max(len(u[3]) for u in utts)
+    smax = max(len(u[0]) for u in utts)
+    pcm = np.zeros((3, smax), dtype=np.float32)
+    tarr = np.full((3, n_max), tok.eot, dtype=np.int64)
+    for i, (p, _, _, toks) in enumerate(utts):
+        pcm[i, :len(p)] = p
+        tarr[i, :len(toks)] = toks
+    opts = model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3)
+    jump, sel = model.align_batch(torch.from_numpy(pcm).cuda(), [len(u[0]) for u in utts], torch.from_numpy(tarr).cuda(),
+                                  [len(u[3]) for u in utts], [len(u[0]) // 320 for u in utts], opts)
+    for i, (p, text, tt, toks) in enumerate(utts):
+        mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=model)
+        w, _ = tm.get_attentions(mel, torch.tensor(toks).cuda(), model, tok, len(p) // 320, medfilt_width=3)
+        words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=4)
+        w2, st2, en2 = tm.words_from_jump_frames(jump[i], tt, tok, "char")
+        assert w2 == words
+        assert np.array_equal(st2, st) and np.array_equal(en2, en)
+        assert list(sel[i]) == [l * dims.n_text_head + h for _, (l, h), _ in scores]
+
+
+def test_too_long_is_rejected(wca, setup):
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    mel = torch.zeros(80, 3000, device="cuda")
+    with pytest.raises(wca._lib.TooLongError):
+        tm.get_attentions(mel, torch.zeros(449, dtype=torch.int64).cuda(), model, tok, 100)
+    with pytest.raises(wca._lib.TooLongError):
+        tm.get_attentions(mel, torch.zeros(10, dtype=torch.int64).cuda(), model, tok, 1501)

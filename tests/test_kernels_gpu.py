@@ -63,7 +63,8 @@ def test_gemm_asymmetric_identity(eng, lib, wca):
     a = torch.eye(M, K).half()
     w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).half()
     out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
-    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a.cuda()), _vp(w.cuda()), None, _vp(out), M, N, K, 0, 1))
+    ad, wd = a.cuda(), w.cuda()  # keep the device copies alive across the launch
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), None, _vp(out), M, N, K, 0, 1))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), w.float().T.contiguous())
 
@@ -98,7 +99,8 @@ def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     out = torch.full((B, nq, d), float("nan"), dtype=torch.float16, device="cuda")
     cap_ld = (cap_cols + 3) & ~3
     cap = torch.full((B, H, nq, max(cap_ld, 4)), float("nan"), device="cuda") if cap_cols else None
-    wca._lib.check(lib.wca_test_attention(eng._h, _vp(q.cuda()), _vp(k.cuda()), _vp(v.cuda()), _vp(out), _vp(cap),
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    wca._lib.check(lib.wca_test_attention(eng._h, _vp(qd), _vp(kd), _vp(vd), _vp(out), _vp(cap),
                                           cap_ld, cap_cols, B, H, nq, nk, causal))
     torch.cuda.synchronize()
     # P is rounded to f16 before P.V and the output is f16: ~1e-3 relative
@@ -115,7 +117,8 @@ def test_layernorm(eng, lib, wca):
         x = torch.randn(37, d, generator=g) * 3 + 1
         gm, bt = torch.randn(d, generator=g), torch.randn(d, generator=g)
         out = torch.empty(37, d, dtype=torch.float16, device="cuda")
-        wca._lib.check(lib.wca_test_layernorm(eng._h, _vp(x.cuda()), _vp(gm.cuda()), _vp(bt.cuda()), _vp(out), 37, d))
+        xd, gd, bd = x.cuda(), gm.cuda(), bt.cuda()
+        wca._lib.check(lib.wca_test_layernorm(eng._h, _vp(xd), _vp(gd), _vp(bd), _vp(out), 37, d))
         torch.cuda.synchronize()
         ref = torch.nn.functional.layer_norm(x, (d,), gm, bt, 1e-5)
         torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
@@ -182,7 +185,8 @@ def test_median_filter_bit_exact(eng, lib, wca, F, w):
     x = torch.randn(37, F, generator=g)
     x[3, : min(F, 20)] = 1.5  # ties
     out = torch.empty_like(x).cuda()
-    wca._lib.check(lib.wca_median_filter(eng._h, _vp(x.cuda()), _vp(out), 37, F, w))
+    xd = x.cuda()
+    wca._lib.check(lib.wca_median_filter(eng._h, _vp(xd), _vp(out), 37, F, w))
     torch.cuda.synchronize()
     ref = timing_ref.median_filter(x.view(1, 1, 37, F), w).reshape(37, F)
     assert torch.equal(out.cpu(), ref)
@@ -195,7 +199,8 @@ def _fa_gpu(eng, lib, wca, A, topk, wc, wr, wv):
     keff = min(topk, L * H)
     idx = np.zeros(keff, dtype=np.int32)
     ss = np.zeros(keff, dtype=np.float32)
-    wca._lib.check(lib.wca_filter_attention(eng._h, _vp(A.cuda().contiguous()), L, H, n, F, topk, wc, wr, wv,
+    Ad = A.cuda().contiguous()
+    wca._lib.check(lib.wca_filter_attention(eng._h, _vp(Ad), L, H, n, F, topk, wc, wr, wv,
                                             sc.ctypes.data_as(C.POINTER(C.c_float)), idx.ctypes.data_as(C.POINTER(C.c_int32)),
                                             ss.ctypes.data_as(C.POINTER(C.c_float))))
     return sc, idx, ss
@@ -238,7 +243,8 @@ def test_force_align_matrix_and_path(eng, lib, wca, aggr, topk):
     k = max(topk, 1)
     sel = np.zeros(k, dtype=np.int32)
     ssc = np.zeros(k, dtype=np.float32)
-    wca._lib.check(lib.wca_force_align(eng._h, _vp(A.cuda()), L, H, n, F, C.byref(opts), mat.ctypes.data_as(C.POINTER(C.c_float)),
+    Ad = A.cuda().contiguous()
+    wca._lib.check(lib.wca_force_align(eng._h, _vp(Ad), L, H, n, F, C.byref(opts), mat.ctypes.data_as(C.POINTER(C.c_float)),
                                        ti.ctypes.data_as(C.POINTER(C.c_int32)), tj.ctypes.data_as(C.POINTER(C.c_int32)),
                                        C.byref(plen), sel.ctypes.data_as(C.POINTER(C.c_int32)), ssc.ctypes.data_as(C.POINTER(C.c_float))))
     ref_m, ref_scores = timing_ref.aggregate(A, aggr, topk)

@@ -65,6 +65,7 @@ SIGNATURES = {
     "wca_test_encoder": (_i, [_vp, _vp, _i, _vp]),
     "wca_last_stage_ms": (_i, [_vp, _pf]),
     "wca_set_profiling": (_i, [_vp, _i]),
+    "wca_last_dominant_kernel_ms": (_i, [_vp, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -19,13 +19,6 @@ N_SAMPLES_PER_TOKEN = HOP_LENGTH * 2         # 320
 FRAMES_PER_SECOND = SAMPLE_RATE // HOP_LENGTH
 TOKENS_PER_SECOND = SAMPLE_RATE // N_SAMPLES_PER_TOKEN  # 50
 
-_default_engine = None
-
-
-def set_default_engine(model):
-    global _default_engine
-    _default_engine = model
-
 
 def _hz_to_mel(f):
     f = np.asarray(f, dtype=np.float64)
@@ -93,9 +86,13 @@ def log_mel_spectrogram(audio, n_mels=80, padding=0, device=None, model=None):
     """whisper.log_mel_spectrogram drop-in: audio f32 [n] or [B, n] (expected already pad_or_trim'ed to
     480000 like dataset.py:47; shorter input is treated as zero padded) -> [n_mels, 3000] f32 on the GPU."""
     import torch
-    eng = model if model is not None else _default_engine
-    if eng is None:
-        raise RuntimeError("log_mel_spectrogram needs a WhisperAMD engine (pass model=... or construct one first)")
+    if model is None:
+        from .engine import default_engine
+        idx = 0
+        if isinstance(audio, torch.Tensor) and audio.is_cuda and audio.device.index is not None:
+            idx = audio.device.index
+        model = default_engine(idx)
+    eng = model
     if eng.dims.n_mels != n_mels:
         raise ValueError("engine was built for n_mels=%d, got %d" % (eng.dims.n_mels, n_mels))
     if not isinstance(audio, torch.Tensor):

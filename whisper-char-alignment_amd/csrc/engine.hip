@@ -150,6 +150,7 @@ struct wca_engine {
   int last_topk = 0, last_ntok_max = 0, last_batch = 0;
 
   hipEvent_t ev[9] = {};
+  hipEvent_t kev[64] = {};   // start/stop pairs around the encoder MLP fc1 GEMM of each layer (dominant kernel)
   bool ev_valid = false;
   float stage_ms[8] = {};
 };
@@ -257,7 +258,7 @@ size_t layout_arena(wca_engine* e, char* base) {
 }
 
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
-                int N, int K, int gelu, int out_mode) {
+                int N, int K, int gelu, int out_mode, int site = 0) {
   GemmArgs g{};
   g.A = A;
   g.lda = lda;
@@ -271,6 +272,7 @@ hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ld
   g.K = K;
   g.gelu = gelu;
   g.out_mode = out_mode;
+  g.site = site;
   return launch_gemm(g, s);
 }
 
@@ -380,6 +382,7 @@ int run_encoder(wca_engine* e, int B) {
     g.K = e->k1pad;
     g.gelu = 1;
     g.out_mode = 0;
+    g.site = 3;
     HIPCHK(launch_gemm(g, s));
   }
   {
@@ -400,6 +403,7 @@ int run_encoder(wca_engine* e, int B) {
     g.K = 3 * d;
     g.gelu = 1;
     g.out_mode = 1;
+    g.site = 3;
     HIPCHK(launch_gemm(g, s));
   }
   const int M = B * N_CTX;
@@ -407,7 +411,7 @@ int run_encoder(wca_engine* e, int B) {
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
     HIPCHK(launch_layernorm_f16(e->x, l.ln1_g, l.ln1_b, e->xn, M, d, 1e-5f, s));
-    HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0));
+    HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0, 1));
     AttnArgs a{};
     a.Q = e->qkv;
     a.K = e->qkv + d;
@@ -424,10 +428,12 @@ int run_encoder(wca_engine* e, int B) {
     a.scale = scale;
     a.causal = 0;
     HIPCHK(launch_attention(a, s));
-    HIPCHK(gemm(s, e->att, d, l.out_w, d, l.out_b, e->x, d, M, d, d, 0, 2));
+    HIPCHK(gemm(s, e->att, d, l.out_w, d, l.out_b, e->x, d, M, d, d, 0, 2, 1));
     HIPCHK(launch_layernorm_f16(e->x, l.ln2_g, l.ln2_b, e->xn, M, d, 1e-5f, s));
-    HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0));
-    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2));
+    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[2 * li], s);
+    HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0, 1));
+    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[2 * li + 1], s);
+    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2, 1));
   }
   HIPCHK(launch_layernorm_f16(e->x, e->lnpost_g, e->lnpost_b, e->xn, M, d, 1e-5f, s));
   return WCA_OK;
@@ -437,7 +443,7 @@ int run_encoder(wca_engine* e, int B) {
 int run_cross_kv(wca_engine* e, int B) {
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
-  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, e->kv, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0));
+  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, e->kv, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0, 3));
   return WCA_OK;
 }
 
@@ -452,7 +458,7 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->dec[li];
     HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, M, 3 * dt, dt, 0, 0));
+    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, M, 3 * dt, dt, 0, 0, 2));
     {
       AttnArgs a{};
       a.Q = e->qkv_d;
@@ -471,9 +477,9 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
       a.causal = 1;
       HIPCHK(launch_attention(a, s));
     }
-    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, M, dt, dt, 0, 2));
+    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, M, dt, dt, 0, 2, 2));
     HIPCHK(launch_layernorm_f16(e->xd, l.lnc_g, l.lnc_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, M, dt, dt, 0, 0));
+    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, M, dt, dt, 0, 0, 2));
     {
       AttnArgs a{};
       a.Q = e->q_d;
@@ -499,14 +505,14 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
       a.causal = 0;
       HIPCHK(launch_attention(a, s));
     }
-    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2));
+    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2, 2));
     HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0));
-    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, M, dt, 4 * dt, 0, 2));
+    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0, 2));
+    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, M, dt, 4 * dt, 0, 2, 2));
   }
   if (logits_out) {
     HIPCHK(launch_layernorm_f16(e->xd, e->lnf_g, e->lnf_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, logits_out, D.n_vocab, M, D.n_vocab, dt, 0, 1));
+    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, logits_out, D.n_vocab, M, D.n_vocab, dt, 0, 1, 3));
   }
   return WCA_OK;
 }
@@ -693,6 +699,7 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   layout_arena(e, e->aslab);
   HIPCHK(hipHostMalloc((void**)&e->meta_host, sizeof(int) * META_SLOTS * 4 * max_batch, hipHostMallocDefault));
   for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
+  for (auto& ev : e->kev) HIPCHK(hipEventCreate(&ev));
   e->ev_valid = true;
   // constant tables of the STFT
   {
@@ -722,14 +729,17 @@ void wca_engine_destroy(wca_engine* e) {
   if (e->meta_host) (void)hipHostFree(e->meta_host);
   if (e->res_host) (void)hipHostFree(e->res_host);
   if (e->ev_valid)
+  {
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->kev) (void)hipEventDestroy(ev);
+  }
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
 
 int wca_engine_set_stream(wca_engine* e, void* hip_stream) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
-  e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+  e->stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream, which is what torch's default stream is
   return WCA_OK;
 }
 
@@ -752,6 +762,24 @@ int wca_last_stage_ms(wca_engine* e, float* ms8) {
   HIPCHK(hipEventSynchronize(e->ev[8]));
   for (int i = 0; i < 7; ++i) HIPCHK(hipEventElapsedTime(&ms8[i], e->ev[i], e->ev[i + 1]));
   HIPCHK(hipEventElapsedTime(&ms8[7], e->ev[0], e->ev[8]));
+  return WCA_OK;
+}
+
+int wca_last_dominant_kernel_ms(wca_engine* e, int* n_launches, float* total_ms, double* flops_per_launch) {
+  if (!e || !n_launches || !total_ms || !flops_per_launch) return fail(WCA_ERR_INVALID, "null argument");
+  if (!e->profiling) return fail(WCA_ERR_STATE, "profiling disabled");
+  HIPCHK(hipEventSynchronize(e->ev[8]));
+  const int nl = e->dims.n_audio_layer < 32 ? e->dims.n_audio_layer : 32;
+  float tot = 0.f;
+  for (int i = 0; i < nl; ++i) {
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e->kev[2 * i], e->kev[2 * i + 1]));
+    tot += ms;
+  }
+  *n_launches = nl;
+  *total_ms = tot;
+  const double d = e->dims.n_audio_state;
+  *flops_per_launch = 2.0 * ((double)e->last_batch * N_CTX) * (4.0 * d) * d;
   return WCA_OK;
 }
 

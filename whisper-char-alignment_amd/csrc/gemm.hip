@@ -29,7 +29,7 @@ __device__ __forceinline__ half8 ldfrag(const half_t* tile, int r, int c) {
   return *reinterpret_cast<const half8*>(tile + r * 64 + ((c ^ swz128(r)) << 3));
 }
 
-template <int OUT_MODE, bool GELU>
+template <int OUT_MODE, bool GELU, int SITE>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -205,16 +205,25 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
   dim3 grid(ntn * ntm), block(256);
   const size_t shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
-#define WCA_LAUNCH(OM, G)                                                                       \
-  do {                                                                                          \
-    static bool attr_set = false;                                                               \
-    if (!attr_set) {                                                                            \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<OM, G>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-      if (e != hipSuccess) return e;                                                            \
-      attr_set = true;                                                                          \
-    }                                                                                           \
-    hipLaunchKernelGGL((gemm_f16_kernel<OM, G>), grid, block, shmem, s, a);                     \
+#define WCA_LAUNCH_S(OM, G, S)                                                                     \
+  do {                                                                                             \
+    static bool attr_set = false;                                                                  \
+    if (!attr_set) {                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<OM, G, S>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
+      if (e != hipSuccess) return e;                                                               \
+      attr_set = true;                                                                             \
+    }                                                                                              \
+    hipLaunchKernelGGL((gemm_f16_kernel<OM, G, S>), grid, block, shmem, s, a);                     \
+  } while (0)
+#define WCA_LAUNCH(OM, G)                       \
+  do {                                          \
+    switch (a.site) {                           \
+      case 1: WCA_LAUNCH_S(OM, G, 1); break;    \
+      case 2: WCA_LAUNCH_S(OM, G, 2); break;    \
+      case 3: WCA_LAUNCH_S(OM, G, 3); break;    \
+      default: WCA_LAUNCH_S(OM, G, 0); break;   \
+    }                                           \
   } while (0)
   if (a.out_mode == 0) {
     if (a.gelu) WCA_LAUNCH(0, true); else WCA_LAUNCH(0, false);
@@ -227,6 +236,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     return hipErrorInvalidValue;
   }
 #undef WCA_LAUNCH
+#undef WCA_LAUNCH_S
   return hipGetLastError();
 }
 

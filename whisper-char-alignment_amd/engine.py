@@ -55,12 +55,31 @@ def dims_for(name):
     return ModelDimensions(n_mels, 1500, d, h, l, n_vocab, 448, d, h, l)
 
 
+_registry = {}   # device index -> weakref of the most recently constructed engine
+_utility = {}    # device index -> weight-less engine created on demand for filter_attention / force_align / dtw
+
+
+def default_engine(device_index=0, need_weights=False):
+    """Most recent live engine on the device; if none exists a tiny weight-less utility engine is
+    created (enough for the ops that take no model argument in the reference API)."""
+    ref = _registry.get(device_index)
+    eng = ref() if ref is not None else None
+    if eng is not None and (eng._finalized or not need_weights):
+        return eng
+    if need_weights:
+        raise RuntimeError("no WhisperAMD engine with weights exists on cuda:%d" % device_index)
+    if device_index not in _utility:
+        _utility[device_index] = WhisperAMD(ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1),
+                                            device="cuda:%d" % device_index, max_batch=1, _register=False)
+    return _utility[device_index]
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
 class WhisperAMD:
-    def __init__(self, dims, device="cuda:0", max_batch=8):
+    def __init__(self, dims, device="cuda:0", max_batch=8, _register=True):
         if not torch.cuda.is_available():
             raise RuntimeError("WhisperAMD needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self._lib = _lib.load()
@@ -75,6 +94,9 @@ class WhisperAMD:
         self._finalized = False
         filt = np.ascontiguousarray(mel_filters(dims.n_mels), dtype=np.float32)
         self._load_one("mel_filters", filt)
+        if _register:
+            import weakref
+            _registry[index] = weakref.ref(self)
 
     # ---- whisper.model.Whisper-like attributes
     @property
@@ -219,6 +241,14 @@ class WhisperAMD:
 
     def set_profiling(self, on):
         _lib.check(self._lib.wca_set_profiling(self._h, 1 if on else 0))
+
+    def dominant_kernel_ms(self):
+        """(launches, summed ms, flops per launch) of the encoder fc1 GEMM in the last align_batch call."""
+        n = C.c_int(0)
+        ms = C.c_float(0)
+        fl = C.c_double(0)
+        _lib.check(self._lib.wca_last_dominant_kernel_ms(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
+        return n.value, ms.value, fl.value
 
     def last_stage_ms(self):
         ms = (C.c_float * 8)()
