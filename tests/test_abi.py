@@ -1,0 +1,62 @@
+"""CPU tests of the drop-in boundary: libwca.so loads without a GPU and exports every symbol that
+include/wca.h declares, with a ctypes signature for each (no compute calls here)."""
+import ctypes
+import importlib
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "wca.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wca_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_hot_path():
+    names = _declared()
+    for need in ["wca_log_mel", "wca_get_attentions", "wca_median_filter", "wca_filter_attention", "wca_force_align", "wca_dtw",
+                 "wca_align_batch", "wca_engine_create", "wca_engine_destroy", "wca_load_weight"]:
+        assert need in names
+
+
+def test_library_exports_every_declared_symbol(wca):
+    lib = wca._lib.load()
+    for name in _declared():
+        assert hasattr(lib, name), "libwca.so does not export %s" % name
+        assert name in wca._lib.SIGNATURES, "no ctypes signature for %s" % name
+    assert set(wca._lib.SIGNATURES) == set(_declared())
+    assert lib.wca_version() >= 1
+    assert isinstance(lib.wca_last_error(), (bytes, type(None)))
+
+
+def test_struct_layouts_match_header(wca):
+    assert ctypes.sizeof(wca._lib.ModelDims) == 10 * 4
+    assert ctypes.sizeof(wca._lib.AlignOpts) == 8 * 4
+    assert [f[0] for f in wca._lib.AlignOpts._fields_] == ["aggregation", "topk", "w_colnorm", "w_rownorm", "w_coverage", "sot_len",
+                                                          "medfilt_width", "qk_scale"]
+
+
+def test_null_engine_is_an_error_not_a_crash(wca):
+    lib = wca._lib.load()
+    assert lib.wca_engine_synchronize(None) < 0
+    assert b"null" in lib.wca_last_error()
+    assert lib.wca_finalize_weights(None) < 0
+
+
+def test_library_is_in_tree_and_has_gfx950_code(wca):
+    path = wca._lib.LIB_PATH
+    assert path.startswith(ROOT) and os.path.exists(path)
+    blob = open(path, "rb").read()
+    assert b"gfx950" in blob and b"gemm_f16_kernel" in blob and b"dtw_kernel" in blob and b"attn_kernel" in blob
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "whisper-char-alignment_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), "%s imports the oracle" % f
+                assert "liboracle" not in text

@@ -1,0 +1,156 @@
+"""CPU tests of the product's host-side logic (no GPU, no oracle in the product path): tokenizer,
+retokenize, metrics, audio readers -- compared with golden vectors produced by the REAL reference files."""
+import importlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _m(name):
+    return importlib.import_module("whisper-char-alignment_amd." + name)
+
+
+@pytest.fixture(scope="module")
+def meta():
+    with open(os.path.join(GOLD, "reference_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def tok():
+    return _m("tokenizer").get_tokenizer(True, language="English")
+
+
+def test_tokenizer_special_ids(tok):
+    tk = _m("tokenizer")
+    assert tok.sot_sequence == (50258, 50259, 50359) and tok.eot == 50257 and tok.no_timestamps == 50363
+    assert tok.timestamp_begin == 50364 and tok.n_vocab == 51865
+    en = tk.get_tokenizer(False)
+    assert en.sot_sequence == (50257,) and en.eot == 50256 and en.no_timestamps == 50362 and en.n_vocab == 51864
+    v3 = tk.get_tokenizer(True, num_languages=100, language="en")
+    assert v3.n_vocab == 51866 and v3.no_timestamps == 50364
+    assert tok.encode(" ") == [220] and tok.encode("a") == [64] and tok.encode("A") == [32] and tok.encode("'") == [6]
+    assert tok.decode([64, 220, 65]) == "a b"
+    with pytest.raises(tk.NeedVocabError):
+        tok.encode("hello")
+    with pytest.raises(ValueError):
+        tk.get_tokenizer(True, language="klingon")
+
+
+def test_retokenize_matches_reference(meta, tok):
+    rt = _m("retokenize")
+    for case in meta["retokenize"]:
+        tt = rt.encode(case["text"], tok, "char")
+        assert tt == case["tokens"]
+        words, wts = rt.split_tokens_on_spaces(tt + [tok.eot], tok, "char")
+        assert words == case["words"] and wts == case["word_tokens"]
+        starts = rt.char_word_starts(tt + [tok.eot], tok)
+        assert list(starts) == list(np.cumsum([0] + [len(w) for w in wts[:-1]]))
+    for text, want in meta["remove_punctuation"]:
+        assert rt.remove_punctuation(text) == want
+
+
+def test_number_to_words():
+    rt = _m("retokenize")
+    assert rt.number_to_words(0) == "zero" and rt.number_to_words(42) == "forty-two"
+    assert rt.number_to_words(101) == "one hundred and one" and rt.number_to_words(1001) == "one thousand and one"
+    assert rt.number_to_words(1234) == "one thousand, two hundred and thirty-four"
+    assert rt.remove_punctuation("room 42") == "room fortytwo"  # the final translate() drops the hyphen, as in the reference
+
+
+def test_metrics_match_reference(meta):
+    mt = _m("metrics")
+    g = meta["metrics"]
+    arrays = np.load(os.path.join(GOLD, "reference_golden.npz"))
+    attn = torch.from_numpy(arrays["cov_attn"])
+    assert float(mt.coverage_penalty(attn)) == pytest.approx(g["coverage_penalty"][0], rel=1e-6)
+    assert float(mt.coverage_penalty(attn, 0.1)) == pytest.approx(g["coverage_penalty"][1], rel=1e-6)
+    for c in g["eval_n1"]:
+        assert list(mt.eval_n1(c["y"], c["yhat"], c["tol"])) == c["out"]
+    for c in g["eval_n1_strict"]:
+        assert list(mt.eval_n1_strict(c["y"], c["yhat"], c["words"], c["words_hat"], c["tol"])) == c["out"]
+    for c in g["get_seg_metrics"]:
+        assert [float(v) for v in mt.get_seg_metrics(*c["args"])] == c["out"]
+
+
+def test_words_from_jump_frames_equals_reference_arithmetic(meta, tok):
+    """The fused path's host tail must reproduce timing.py:108-113 given the DTW path."""
+    tm = _m("timing")
+    arrays = np.load(os.path.join(GOLD, "reference_golden.npz"))
+    from oracle import timing_ref
+    for case in meta["force_align"]:
+        if case["degenerate"]:
+            w, st, en = tm.words_from_jump_frames(np.zeros(len(case["tokens"]) + 1, dtype=np.int32), case["tokens"], tok, "char")
+            assert w == [] and len(st) == 0
+            continue
+        matrix = torch.from_numpy(arrays[case["ws"] + "_matrix"])
+        ti, tj = timing_ref.dtw(-matrix)
+        jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+        words, st, en = tm.words_from_jump_frames(tj[jumps], case["tokens"], tok, "char")
+        assert words == case["words"]
+        np.testing.assert_array_equal(st, arrays[case["ws"] + "_start"])
+        np.testing.assert_array_equal(en, arrays[case["ws"] + "_end"])
+
+
+def test_audio_readers(tmp_path):
+    au = _m("audio")
+    pcm = (np.load(os.path.join(GOLD, "sample_pcm_int16.npy")))
+    # RIFF/WAVE 16-bit
+    p = tmp_path / "a.wav"
+    data = pcm.astype("<i2").tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16)
+    p.write_bytes(hdr + b"data" + struct.pack("<I", len(data)) + data)
+    x, sr = au.load_audio(str(p))
+    assert sr == 16000 and np.array_equal(np.round(x * 32768).astype(np.int16), pcm)
+    # NIST SPHERE (what TIMIT's ".wav" files are, like sample/test.wav)
+    s = tmp_path / "b.wav"
+    head = ("NIST_1A\n   1024\nsample_count -i %d\nsample_rate -i 16000\nchannel_count -i 1\nsample_n_bytes -i 2\n"
+            "sample_byte_format -s2 01\nsample_coding -s3 pcm\nend_head\n" % len(pcm)).encode()
+    s.write_bytes(head + b" " * (1024 - len(head)) + data)
+    y, sr = au.load_audio(str(s))
+    assert sr == 16000 and np.array_equal(np.round(y * 32768).astype(np.int16), pcm)
+    assert len(pcm) == 46592 and len(pcm) // 320 == 145  # sample/test.wav -> 145 frames
+    with pytest.raises(ValueError):
+        bad = tmp_path / "c.wav"
+        bad.write_bytes(b"garbage")
+        au.load_audio(str(bad))
+
+
+def test_pad_or_trim_and_filters():
+    au = _m("audio")
+    assert au.pad_or_trim(np.ones(10), 16).shape == (16,) and au.pad_or_trim(np.ones(20), 16).shape == (16,)
+    t = au.pad_or_trim(torch.ones(2, 10), 16)
+    assert t.shape == (2, 16) and float(t[:, 10:].abs().sum()) == 0.0
+    f80, f128 = au.mel_filters(80), au.mel_filters(128)
+    assert f80.shape == (80, 201) and f128.shape == (128, 201) and (f80 >= 0).all()
+    from transformers.audio_utils import mel_filter_bank
+    hf = mel_filter_bank(201, 80, 0.0, 8000.0, 16000, norm="slaney", mel_scale="slaney").T
+    assert np.abs(hf - f80).max() < 1e-7
+
+
+def test_synthetic_inputs_are_deterministic():
+    syn = _m("synthetic")
+    a, b = syn.synth_audio(3, 16000), syn.synth_audio(3, 16000)
+    assert np.array_equal(a, b) and a.dtype == np.float32 and np.abs(a).max() <= 1.0
+    assert (a[2000:4000] == 0).all() and np.abs(a[:2000]).max() > 0  # 4 Hz gate: 125 ms on / 125 ms off
+    for u in range(20):
+        t = syn.synth_text(u, 64)
+        assert len(t) == 64 and t == t.strip() and "  " not in t and all(2 <= len(w) for w in t.split())
+
+
+def test_product_refuses_to_run_without_gpu():
+    """No CPU fallback: constructing an engine on a GPU-less box must fail loudly."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    wca = importlib.import_module("whisper-char-alignment_amd")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        wca.WhisperAMD(wca.dims_for("tiny"))
+    tm = _m("timing")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tm.filter_attention(torch.rand(2, 2, 4, 8).softmax(-1), topk=1)

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void dtw_kernel(DtwArgs a) {
   __threadfence();  // trace words written by all lanes -> visible to lane 0's loads below
   if (lane == 0) {
     int i = N - 1, j = M - 1, k = cap;
-    int* jf = a.jump_frame ? a.jump_frame + (long)p * a.N_max : nullptr;
+    int* jf = a.jump_frame ? a.jump_frame + (long)p * a.jump_ld : nullptr;
     while ((i >= 0 || j >= 0) && k > 0) {
       --k;
       pt[k] = i;

@@ -645,6 +645,7 @@ int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH,
     dg.path = (int*)e->path.p;
     dg.path_len = (int*)e->pathlen.p;
     dg.jump_frame = (int*)e->jump.p;
+    dg.jump_ld = n_max;
     dg.P = B;
     HIPCHK(launch_dtw(dg, s));
   }
@@ -1073,6 +1074,7 @@ static int dtw_dev_common(wca_engine* e, const float* matrix_dev, int P, int N, 
   dg.path = (int*)e->path.p;
   dg.path_len = (int*)e->pathlen.p;
   dg.jump_frame = want_jump ? (int*)e->jump.p : nullptr;
+  dg.jump_ld = N;
   dg.P = P;
   HIPCHK(launch_dtw(dg, e->stream));
   return WCA_OK;

@@ -124,7 +124,8 @@ struct DtwArgs {
   uint32_t* trace;         // workspace: P * N_max * ceil(M_max/16) words
   int* path;               // [P][2][cap] text idx row then time idx row, right-aligned; cap = N_max + M_max + 2
   int* path_len;           // [P]
-  int* jump_frame;         // [P][N_max] first frame of each text row (or nullptr)
+  int* jump_frame;         // [P][jump_ld] first frame of each text row (or nullptr)
+  int jump_ld;             // row stride of jump_frame (>= N_max)
   int P;
 };
 hipError_t launch_dtw(const DtwArgs& a, hipStream_t s);
