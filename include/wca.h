@@ -18,6 +18,7 @@
  *                          aggregation "mean" (timing.py:84-89) / "topk" (timing.py:91-97), the
  *                          [len(sot_sequence):-1] slice (timing.py:102), DTW + backtrace (timing.py:103)
  *   wca_dtw                timing.py:103     whisper.timing.dtw -> dtw_cpu + backtrace
+ *   wca_probe_heads        probe_oracle.py:83-90  per-head force_align sweep (one DTW per head)
  *   wca_align_batch        infer_ali.py:93-101 + dataset.py:47-48: the whole per-utterance pipeline
  *                          (log-mel -> forward+capture -> medfilt/softmax -> scores/top-k ->
  *                          aggregate -> DTW) for a micro-batch of utterances, results = the frame
@@ -138,6 +139,12 @@ int wca_dtw(wca_engine* e, const float* matrix_host, int N, int M, int32_t* text
 /* Same for P independent problems already in HBM (probe_oracle.py:88-90: one DTW per head).
  * matrix_dev [P][N][M]; jump_frame_host [P][N]: frame at which the path enters each row. */
 int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int M, int32_t* jump_frame_host);
+
+/* probe_oracle.py:83-90: one alignment PER HEAD (aggregation "mean" on a single head = column
+ * normalisation only), all L*H DTWs in one launch. ws_dev [L][H][n][F]; scores_host [L*H] = the
+ * filter_attention scores (w_col = w_row = 1); jump_frame_host [L*H][n - sot_len - 1]. */
+int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, int sot_len, float* scores_host,
+                    int32_t* jump_frame_host);
 
 /* Fused per-utterance pipeline for a micro-batch (the north-star hot path).
  * pcm_dev [batch][pcm_stride] f32; tokens_dev [batch][n_tok_max] int64; n_tok_host, n_samples_host,

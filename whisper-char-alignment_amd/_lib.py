@@ -56,6 +56,7 @@ SIGNATURES = {
     "wca_force_align": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(AlignOpts), _pf, _pi32, _pi32, _pi32, _pi32, _pf]),
     "wca_dtw": (_i, [_vp, _pf, _i, _i, _pi32, _pi32, _pi32]),
     "wca_dtw_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _pi32]),
+    "wca_probe_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _pf, _pi32]),
     "wca_align_batch": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts), _pi32, _pi32]),
     "wca_align_batch_enqueue": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts)]),
     "wca_align_batch_fetch": (_i, [_vp, _i, _i, _i, _pi32, _pi32]),

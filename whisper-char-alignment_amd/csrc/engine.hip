@@ -1113,6 +1113,67 @@ int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int 
   return WCA_OK;
 }
 
+int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, int sot_len, float* scores_host,
+                    int32_t* jump_frame_host) {
+  if (!e || !ws_dev || !jump_frame_host) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  const int LH = L * H, N = n - sot_len - 1;
+  if (sot_len < 0 || N < 1) return fail(WCA_ERR_INVALID, "n=%d leaves no rows after the [sot_len:-1] slice", n);
+  int* rows[4];
+  int rc = stats_on_weights(e, ws_dev, L, H, n, F, 1.f, 1.f, 0.f, rows, N);
+  if (rc) return rc;
+  // every head becomes its own "utterance": matrix_h = ws_h / ||ws_h||_col  (timing.py:84-89 with L = H = 1)
+  HIPCHK(e->tmp1.ensure(sizeof(int) * 2 * (size_t)LH));
+  std::vector<int> meta(2 * (size_t)LH);
+  for (int i = 0; i < LH; ++i) {
+    meta[i] = n;
+    meta[LH + i] = F;
+  }
+  HIPCHK(hipMemcpyAsync(e->tmp1.p, meta.data(), sizeof(int) * 2 * LH, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // meta is a stack-lifetime host buffer
+  HIPCHK(e->matrix.ensure(sizeof(float) * (size_t)LH * n * F));
+  AggregateArgs g{};
+  g.weights = ws_dev;
+  g.w_bs = (long)n * F;
+  g.n_tok_max = n;
+  g.n_frames_max = F;
+  g.colnorm = (const float*)e->colnorm.p;
+  g.sel_idx = nullptr;
+  g.head_lo = 0;
+  g.LH = 1;
+  g.B = LH;
+  g.n_tok = (const int*)e->tmp1.p;
+  g.n_frames = (const int*)e->tmp1.p + LH;
+  g.row_lo = sot_len;
+  g.row_hi_trim = 1;
+  g.matrix = (float*)e->matrix.p;
+  HIPCHK(launch_aggregate(g, e->stream));
+  const int wpr = (F + 15) / 16, cap = N + F + 2;
+  HIPCHK(e->trace.ensure(sizeof(uint32_t) * (size_t)LH * N * wpr));
+  HIPCHK(e->path.ensure(sizeof(int) * (size_t)LH * 2 * cap));
+  HIPCHK(e->pathlen.ensure(sizeof(int) * (size_t)LH));
+  HIPCHK(e->jump.ensure(sizeof(int) * (size_t)LH * N));
+  DtwArgs dg{};
+  dg.matrix = (const float*)e->matrix.p;
+  dg.m_bs = (long)n * F;
+  dg.ld = F;
+  dg.N_all = N;
+  dg.M_all = F;
+  dg.N_max = N;
+  dg.M_max = F;
+  dg.trace = (uint32_t*)e->trace.p;
+  dg.path = (int*)e->path.p;
+  dg.path_len = (int*)e->pathlen.p;
+  dg.jump_frame = (int*)e->jump.p;
+  dg.jump_ld = N;
+  dg.P = LH;
+  HIPCHK(launch_dtw(dg, e->stream));
+  HIPCHK(hipMemcpyAsync(jump_frame_host, e->jump.p, sizeof(int) * (size_t)LH * N, hipMemcpyDeviceToHost, e->stream));
+  if (scores_host) HIPCHK(hipMemcpyAsync(scores_host, e->scores.p, sizeof(float) * LH, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
 int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
                             const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host, const int32_t* max_frames_host,
                             int batch, const wca_align_opts* o) {

@@ -1,0 +1,147 @@
+"""Corpus wrappers with the reference's names (dataset.py:14-122): TIMIT and LibriSpeech datasets driven
+by a Kaldi-style `.scp` list (`<fid> <path>` per line, README.md:55-62), plus Collate.
+
+Differences from the reference, all on the I/O side (the per-item tuple is unchanged):
+  * audio is read lazily (the reference's TIMIT loads the whole corpus in __init__, dataset.py:26-36);
+  * no torchaudio: NIST SPHERE / RIFF WAV are parsed by audio.load_audio (TIMIT '.wav' files are SPHERE);
+    FLAC (LibriSpeech) needs the optional `soundfile` package and fails with a clear message without it;
+  * `ls_alignment_{split}.txt` lines are parsed with ast.literal_eval instead of eval (dataset.py:87);
+  * the log-mel is computed on the GPU by the engine (csrc/logmel.hip) instead of torch.stft on the host;
+    `__getitem__` returns mel=None when constructed with compute_mel=False (the fused batch path takes PCM).
+Item tuple: (audio, mel, duration, text, starts, ends, fid)  -- duration = number of samples before padding.
+"""
+import ast
+import os
+from glob import glob
+
+import numpy as np
+import torch
+
+from . import audio as _audio
+
+
+def _load_mono(path):
+    try:
+        pcm, sr = _audio.load_audio(path)
+    except ValueError:
+        try:
+            import soundfile as sf
+        except ImportError:
+            raise RuntimeError("%s is neither NIST SPHERE nor RIFF/WAVE and the optional `soundfile` package (needed for "
+                               "FLAC) is not installed; convert the corpus to 16 kHz WAV" % path)
+        pcm, sr = sf.read(path, dtype="float32", always_2d=False)
+        pcm = pcm.T
+    pcm = np.asarray(pcm, dtype=np.float32)
+    if pcm.ndim > 1:
+        pcm = pcm.reshape(-1) if pcm.shape[0] == 1 else pcm[0]
+    return pcm, sr
+
+
+class Collate:
+    """batch_size=1 collate of the reference (dataset.py:14-18): unwraps the single item."""
+
+    def __call__(self, batch):
+        audio, mel, duration, text, starts, ends, fid = list(zip(*batch))
+        return audio[0], mel[0], duration[0], text[0], starts[0], ends[0], fid[0]
+
+
+class _ScpDataset(torch.utils.data.Dataset):
+    sample_rate = 16000
+
+    def __init__(self, n_mels=80, device="cpu", model=None, compute_mel=True):
+        self.n_mels = n_mels
+        self.device = device
+        self.model = model
+        self.compute_mel = compute_mel
+        self.items = []
+
+    def __len__(self):
+        return len(self.items)
+
+    def duration_hint(self, i):
+        """Cheap length estimate (bytes on disk) used to balance shards; exact duration needs a decode."""
+        try:
+            return os.path.getsize(self.items[i][0])
+        except OSError:
+            return 0
+
+    def _audio_and_mel(self, path):
+        pcm, sr = _load_mono(path)
+        assert sr == self.sample_rate
+        duration = len(pcm)
+        audio = _audio.pad_or_trim(torch.from_numpy(pcm))
+        mel = None
+        if self.compute_mel:
+            mel = _audio.log_mel_spectrogram(audio, self.n_mels, model=self.model)
+        return audio, mel, duration
+
+
+class TIMIT(_ScpDataset):
+    """scp lines `<fid> <path/to/x.wav>`; word ground truth in the sibling `.wrd` file
+    (`<start_sample> <end_sample> <word>` per line, dataset.py:53-64)."""
+
+    def __init__(self, scp_file="scp/test.wav.scp", n_mels=80, device="cpu", model=None, compute_mel=True):
+        super().__init__(n_mels, device, model, compute_mel)
+        with open(scp_file) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 2:
+                    fid, path = parts[0], parts[1]
+                    self.items.append((path, path.split(".wav")[0] + ".wrd", fid))
+
+    def process_text(self, filename):
+        starts, ends, words = [], [], []
+        with open(filename) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 3:
+                    starts.append(float(parts[0]) / self.sample_rate)
+                    ends.append(float(parts[1]) / self.sample_rate)
+                    words.append(parts[2])
+        return " ".join(words), starts, ends
+
+    def __getitem__(self, i):
+        path, wrd, fid = self.items[i]
+        text, starts, ends = self.process_text(wrd)
+        audio, mel, duration = self._audio_and_mel(path)
+        return audio, mel, duration, text, starts, ends, fid
+
+
+class LibriSpeech(_ScpDataset):
+    """scp lines `<fid> <root>/<split>/<spk>/<chap>/<fid>.flac`; transcripts from `*.trans.txt`, word
+    alignments from `ls_alignment_{split}.txt` lines `<fid> [(word, start, end), ...]` (dataset.py:67-122).
+    Audio longer than 30 s is trimmed, as in the reference."""
+
+    def __init__(self, scp_file="scp/dev-clean.wav.scp", n_mels=80, device="cpu", model=None, compute_mel=True, alignment_file=None):
+        super().__init__(n_mels, device, model, compute_mel)
+        with open(scp_file) as f:
+            scp = [l for l in f if l.strip()]
+        first_path = scp[0].split()[1]
+        split = first_path.split("/")[-4]
+        root = first_path.split(split)[0]
+        labels = {}
+        for trans in sorted(glob(os.path.join(root, split, "**/*.trans.txt"), recursive=True)):
+            with open(trans) as f:
+                for line in f:
+                    fid, text = line.split(" ", 1)
+                    labels[fid] = text
+        ali = {}
+        with open(alignment_file or "ls_alignment_%s.txt" % split) as f:
+            for line in f:
+                fid, rest = line.split(" ", 1)
+                ali[fid] = ast.literal_eval(rest.strip())
+        for line in scp:
+            fid, path = line.split()[:2]
+            self.items.append((path, labels[fid], ali[fid], fid))
+
+    def __getitem__(self, i):
+        path, _text, ali, fid = self.items[i]
+        audio, mel, duration = self._audio_and_mel(path)
+        starts, ends, words = [], [], []
+        for item in ali:
+            if item[0] == "":
+                continue
+            words.append(item[0])
+            starts.append(item[1])
+            ends.append(item[2])
+        return audio, mel, duration, " ".join(words), starts, ends, fid
