@@ -166,7 +166,8 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
                           int32_t* sel_idx_host);
 
 /* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
-/* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device, out f32 device */
+/* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device. out_mode low byte: 0 f16 store, 1 f32 store,
+ * 2 f32 accumulate; out_mode >> 8: force the tile shape (0 auto, 128, 256). */
 int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                   int N, int K, int gelu, int out_mode);
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL */

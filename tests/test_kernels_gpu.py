@@ -28,7 +28,8 @@ def eng(wca):
 # ------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1500, 1152, 384), (77, 130, 64), (128, 128, 64), (3000, 384, 256)])
 @pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
-def test_gemm(eng, lib, wca, M, N, K, mode):
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm(eng, lib, wca, M, N, K, mode, tile):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = (torch.randn(M, K, generator=g) * 0.5).half()
     w = (torch.randn(N, K, generator=g) * 0.1).half()
@@ -38,7 +39,7 @@ def test_gemm(eng, lib, wca, M, N, K, mode):
     if mode == "f16" or mode == "f16_gelu":
         out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
         gelu = int(mode == "f16_gelu")
-        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0))
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0 | (tile << 8)))
         if gelu:
             ref = torch.nn.functional.gelu(ref)
         torch.cuda.synchronize()
@@ -46,25 +47,41 @@ def test_gemm(eng, lib, wca, M, N, K, mode):
         torch.testing.assert_close(out.float().cpu(), ref, rtol=2e-3, atol=2e-3)
     elif mode == "f32":
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 1))
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 1 | (tile << 8)))
         torch.cuda.synchronize()
         torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
     else:
         base = torch.randn(M, N, generator=g)
         out = base.clone().cuda()
-        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2))
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2 | (tile << 8)))
         torch.cuda.synchronize()
         torch.testing.assert_close(out.cpu(), base + ref, rtol=1e-4, atol=1e-4)
 
 
-def test_gemm_asymmetric_identity(eng, lib, wca):
+@pytest.mark.parametrize("M,N,K", [(2000, 768, 1024), (515, 1024, 4096), (4096, 256, 64)])
+def test_gemm_256_tile_long_k_and_tails(eng, lib, wca, M, N, K):
+    """The 256x256 kernel's DMA ring (prefetch distance 2, counted vmcnt) over many K tiles and ragged M."""
+    g = torch.Generator().manual_seed(K + M)
+    a = (torch.randn(M, K, generator=g) * 0.3).half()
+    w = (torch.randn(N, K, generator=g) * 0.05).half()
+    ref = a.float() @ w.float().T
+    ad, wd = a.cuda(), w.cuda()
+    for _ in range(3):  # repeated launches: a stale-ring race would show up as run-to-run differences
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), None, _vp(out), M, N, K, 0, 1 | (256 << 8)))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.cpu(), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_asymmetric_identity(eng, lib, wca, tile):
     """A = I with an asymmetric W catches a transposed / permuted C write."""
-    M = N = K = 128
+    M = N = K = 128 if tile == 128 else 256
     a = torch.eye(M, K).half()
     w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 - 125).half()
     out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
     ad, wd = a.cuda(), w.cuda()  # keep the device copies alive across the launch
-    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), None, _vp(out), M, N, K, 0, 1))
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), None, _vp(out), M, N, K, 0, 1 | (tile << 8)))
     torch.cuda.synchronize()
     assert torch.equal(out.cpu(), w.float().T.contiguous())
 

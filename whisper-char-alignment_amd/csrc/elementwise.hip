@@ -8,48 +8,82 @@ namespace wca {
 
 namespace {
 
-// d % 128 == 0, d <= 128 * MAXP (Whisper: 384..1280)
-constexpr int MAXP = 10;
-
-__global__ __launch_bounds__(256) void layernorm_f16_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, half_t* __restrict__ out,
-                                                            int rows, int d, float eps) {
+// One wave per row, the whole row in registers (two passes over registers, one over HBM).
+// NV = 16-byte vectors per lane: d = 256 * NV (d = 256 .. 1280); d = 128 / 384 use the 8-byte variant.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_f16_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, half_t* __restrict__ out,
+                                                               int rows, float eps) {
+  constexpr int d = 256 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const int nper = d >> 7;  // float2 per lane
-  const f32x2* xr = reinterpret_cast<const f32x2*>(x + (long)row * d);
-  f32x2 v[MAXP];
+  const f32x4* xr = reinterpret_cast<const f32x4*>(x + (long)row * d);
+  f32x4 v[NV];
   float s = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    if (i < nper) {
-      v[i] = xr[i * 64 + lane];
-      s += v[i][0] + v[i][1];
-    }
+  for (int i = 0; i < NV; ++i) {
+    v[i] = xr[i * 64 + lane];
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
-  const float mean = wave_sum(s) / (float)d;
+  const float mean = wave_sum(s) * (1.0f / d);
   float q = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    if (i < nper) {
-      const float a = v[i][0] - mean, b = v[i][1] - mean;
-      q += a * a + b * b;
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = v[i][j] - mean;
+      q += t * t;
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + eps);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
+  half4* o4 = reinterpret_cast<half4*>(out + (long)row * d);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const f32x4 g = g4[i * 64 + lane], bb = b4[i * 64 + lane];
+    half4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (half_t)((v[i][j] - mean) * rstd * g[j] + bb[j]);
+    o4[i * 64 + lane] = o;
+  }
+}
+
+template <int NV2>  // d = 128 * NV2
+__global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, half_t* __restrict__ out,
+                                                               int rows, float eps) {
+  constexpr int d = 128 * NV2;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f32x2* xr = reinterpret_cast<const f32x2*>(x + (long)row * d);
+  f32x2 v[NV2];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV2; ++i) {
+    v[i] = xr[i * 64 + lane];
+    s += v[i][0] + v[i][1];
+  }
+  const float mean = wave_sum(s) * (1.0f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV2; ++i) {
+    const float a = v[i][0] - mean, b = v[i][1] - mean;
+    q += a * a + b * b;
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + eps);
   const f32x2* g2 = reinterpret_cast<const f32x2*>(gamma);
   const f32x2* b2 = reinterpret_cast<const f32x2*>(beta);
   half2_* o2 = reinterpret_cast<half2_*>(out + (long)row * d);
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) {
-    if (i < nper) {
-      const f32x2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
-      half2_ o;
-      o[0] = (half_t)((v[i][0] - mean) * rstd * g[0] + bb[0]);
-      o[1] = (half_t)((v[i][1] - mean) * rstd * g[1] + bb[1]);
-      o2[i * 64 + lane] = o;
-    }
+  for (int i = 0; i < NV2; ++i) {
+    const f32x2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
+    half2_ o;
+    o[0] = (half_t)((v[i][0] - mean) * rstd * g[0] + bb[0]);
+    o[1] = (half_t)((v[i][1] - mean) * rstd * g[1] + bb[1]);
+    o2[i * 64 + lane] = o;
   }
 }
 
@@ -83,8 +117,17 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restri
 hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int rows, int d,
                                 float eps, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
-  if ((d % 128) != 0 || d > 128 * MAXP) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(layernorm_f16_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, x, gamma, beta, out, rows, d, eps);
+  dim3 grid((rows + 3) / 4), block(256);
+  switch (d) {
+    case 128: hipLaunchKernelGGL((layernorm_f16_v2_kernel<1>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 256: hipLaunchKernelGGL((layernorm_f16_v4_kernel<1>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 384: hipLaunchKernelGGL((layernorm_f16_v2_kernel<3>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 512: hipLaunchKernelGGL((layernorm_f16_v4_kernel<2>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 768: hipLaunchKernelGGL((layernorm_f16_v4_kernel<3>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 1024: hipLaunchKernelGGL((layernorm_f16_v4_kernel<4>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 1280: hipLaunchKernelGGL((layernorm_f16_v4_kernel<5>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    default: return hipErrorInvalidValue;
+  }
   return hipGetLastError();
 }
 

@@ -1283,7 +1283,21 @@ int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, con
 int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias, void* c, int M, int N, int K, int gelu, int out_mode) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   HIPCHK(hipSetDevice(e->device));
-  HIPCHK(gemm(e->stream, (const half_t*)a, K, (const half_t*)w, K, bias, c, N, M, N, K, gelu, out_mode));
+  GemmArgs g{};
+  g.A = (const half_t*)a;
+  g.lda = K;
+  g.W = (const half_t*)w;
+  g.ldw = K;
+  g.bias = bias;
+  g.C = c;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.gelu = gelu;
+  g.out_mode = out_mode & 0xff;
+  g.force_tile = out_mode >> 8;  // 0 auto / 128 / 256
+  HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }
 

@@ -29,6 +29,77 @@ __device__ __forceinline__ half8 ldfrag(const half_t* tile, int r, int c) {
   return *reinterpret_cast<const half8*>(tile + r * 64 + ((c ^ swz128(r)) << 3));
 }
 
+// Epilogue shared by both tile shapes. Lane (fr, fg) holds, for m-tile mt, the 16 consecutive outputs
+// C[m = mbase + mt*16 + fr][n = nb + nt*4 + r]  (nt, r = 0..3).
+template <int OUT_MODE, bool GELU, int MT>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4], int mbase, int nb, int fr) {
+  float bv[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) bv[j] = (a.bias != nullptr && nb + j < a.N) ? a.bias[nb + j] : 0.f;
+  const bool full_n = (nb + 16 <= a.N);
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mbase + mt * 16 + fr;
+    if (m >= a.M) continue;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
+    if (GELU) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (a.pos != nullptr) {
+      const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nb;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < a.N) v[j] += pp[j];
+    }
+    long coff;
+    if (a.c_rows_per_batch > 0) {
+      const int b = m / a.c_rows_per_batch;
+      const int t = m - b * a.c_rows_per_batch;
+      coff = (long)b * a.c_batch_stride + (long)t * a.ldc;
+    } else {
+      coff = (long)m * a.ldc;
+    }
+    if (OUT_MODE == 0) {
+      half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
+        half8 h0, h1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          h0[j] = (half_t)v[j];
+          h1[j] = (half_t)v[8 + j];
+        }
+        reinterpret_cast<half8*>(cp)[0] = h0;
+        reinterpret_cast<half8*>(cp)[1] = h1;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (nb + j < a.N) cp[j] = (half_t)v[j];
+      }
+    } else {
+      float* cp = reinterpret_cast<float*>(a.C) + coff + nb;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
+        f32x4* c4 = reinterpret_cast<f32x4*>(cp);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4 o = f32x4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
+          if (OUT_MODE == 2) o += c4[q];
+          c4[q] = o;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (nb + j < a.N) cp[j] = (OUT_MODE == 2) ? cp[j] + v[j] : v[j];
+      }
+    }
+  }
+}
+
 template <int OUT_MODE, bool GELU, int SITE>
 __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,73 +198,136 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
     cur ^= 1;
   }
 
-  // ---- epilogue: lane (fr, fg) holds C[m = m0 + wm*64 + mt*16 + fr][n = n0 + wn*64 + fg*16 + nt*4 + r]
-  const int nb = n0 + wn * 64 + fg * 16;
-  float bv[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) bv[j] = (a.bias != nullptr && nb + j < a.N) ? a.bias[nb + j] : 0.f;
-  const bool full_n = (nb + 16 <= a.N);
+  epilogue<OUT_MODE, GELU, 4>(a, acc, m0 + wm * 64, n0 + wn * 64 + fg * 16, fr);
+}
 
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 512 threads = 8 waves (2 along M x 4 along N, 128 x 64 outputs per wave),
+// one workgroup per CU. LDS: ring of two K tiles, each [A 256x64 | W 256x64] f16 = 64 KiB (128 KiB).
+// K tile t+2 is requested (LDS-DMA, 8 x 1 KiB per wave) in the MIDDLE of K tile t, right after the last
+// ds_read of the ring slot it overwrites, and is only waited for at the top of K tile t+2 with a COUNTED
+// vmcnt (the 8 requests of tile t+3 stay in flight) followed by a raw s_barrier -- the loads never drain
+// inside the loop. Two barriers per K tile:
+//   B1 (top)   : every wave's DMA for this tile has landed        (RAW; reads come after the barrier)
+//   B2 (middle): every wave has finished reading this ring slot   (WAR; the refill is issued after it)
+template <int OUT_MODE, bool GELU, int SITE>
+__global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+  constexpr int TILE256 = 256 * 64;  // one operand K tile (f16 elements)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int ntn = (a.N + 255) / 256;
+  const int ntm = (a.M + 255) / 256;
+  const int nwg = ntm * ntn;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const half_t* asrc[4];
+  const half_t* wsrc[4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + fr;
-    if (m >= a.M) continue;
-    float v[16];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
-    if (GELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-    }
-    if (a.pos != nullptr) {
-      const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nb;
-#pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (nb + j < a.N) v[j] += pp[j];
-    }
-    long coff;
-    if (a.c_rows_per_batch > 0) {
-      const int b = m / a.c_rows_per_batch;
-      const int t = m - b * a.c_rows_per_batch;
-      coff = (long)b * a.c_batch_stride + (long)t * a.ldc;
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ swz128(r);
+    int gm = m0 + r;
+    gm = gm < a.M ? gm : a.M - 1;
+    long aoff;
+    if (a.a_rows_per_batch > 0) {
+      const int b = gm / a.a_rows_per_batch;
+      const int t = gm - b * a.a_rows_per_batch;
+      aoff = (long)b * a.a_batch_stride + (long)t * a.lda;
     } else {
-      coff = (long)m * a.ldc;
+      aoff = (long)gm * a.lda;
     }
-    if (OUT_MODE == 0) {
-      half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
-      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
-        half8 h0, h1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          h0[j] = (half_t)v[j];
-          h1[j] = (half_t)v[8 + j];
-        }
-        reinterpret_cast<half8*>(cp)[0] = h0;
-        reinterpret_cast<half8*>(cp)[1] = h1;
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (nb + j < a.N) cp[j] = (half_t)v[j];
-      }
-    } else {
-      float* cp = reinterpret_cast<float*>(a.C) + coff + nb;
-      if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
-        f32x4* c4 = reinterpret_cast<f32x4*>(cp);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          f32x4 o = f32x4{v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-          if (OUT_MODE == 2) o += c4[q];
-          c4[q] = o;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (nb + j < a.N) cp[j] = (OUT_MODE == 2) ? cp[j] + v[j] : v[j];
-      }
-    }
+    asrc[i] = a.A + aoff + c * 8;
+    int gn = n0 + r;
+    gn = gn < a.N ? gn : a.N - 1;
+    wsrc[i] = a.W + (long)gn * a.ldw + c * 8;
   }
+
+  auto stage = [&](int buf, int k0) {
+    half_t* At = lds + buf * (2 * TILE256);
+    half_t* Wt = At + TILE256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rbase = (wave * 4 + i) * 8;
+      glds16(asrc[i] + k0, At + rbase * 64);
+      glds16(wsrc[i] + k0, Wt + rbase * 64);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  int xrow[8], wrow[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) xrow[t] = wr * 128 + t * 16 + fr;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wrow[t] = wc * 64 + (fr >> 2) * 16 + t * 4 + (fr & 3);
+
+  const int nk = a.K / BK;
+  stage(0, 0);
+  if (nk > 1) stage(1, BK);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    const half_t* At = lds + cur * (2 * TILE256);
+    const half_t* Wt = At + TILE256;
+    if (kt + 1 < nk) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    half8 wf[2][4], xf[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wf[ks][t] = ldfrag(Wt, wrow[t], ks * 4 + fg);
+        xf[ks][t] = ldfrag(At, xrow[t], ks * 4 + fg);
+      }
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][nt], xf[ks][mt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+
+    half8 xg[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xg[ks][t] = ldfrag(At, xrow[4 + t], ks * 4 + fg);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[4 + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][nt], xg[ks][mt], acc[4 + mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
 }
 
 }  // namespace
@@ -202,28 +336,45 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || (a.K % BK) != 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
-  const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-  dim3 grid(ntn * ntm), block(256);
-  const size_t shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
-#define WCA_LAUNCH_S(OM, G, S)                                                                     \
-  do {                                                                                             \
-    static bool attr_set = false;                                                                  \
-    if (!attr_set) {                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_f16_kernel<OM, G, S>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);  \
-      if (e != hipSuccess) return e;                                                               \
-      attr_set = true;                                                                             \
-    }                                                                                              \
-    hipLaunchKernelGGL((gemm_f16_kernel<OM, G, S>), grid, block, shmem, s, a);                     \
+  // tile choice: the 256^2 kernel runs one workgroup per CU, so it needs about a full wave of 256 workgroups
+  const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+  const bool big = (a.force_tile == 256) || (a.force_tile == 0 && tiles256 >= 192);
+  dim3 grid, block;
+  size_t shmem;
+  if (big) {
+    grid = dim3((unsigned)tiles256);
+    block = dim3(512);
+    shmem = 2 * 2 * 256 * 64 * sizeof(half_t);  // 128 KiB
+  } else {
+    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+    grid = dim3(ntn * ntm);
+    block = dim3(256);
+    shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
+  }
+#define WCA_LAUNCH_K(KERN, OM, G, S)                                                              \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S>),           \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return e;                                                              \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
-#define WCA_LAUNCH(OM, G)                       \
-  do {                                          \
-    switch (a.site) {                           \
-      case 1: WCA_LAUNCH_S(OM, G, 1); break;    \
-      case 2: WCA_LAUNCH_S(OM, G, 2); break;    \
-      case 3: WCA_LAUNCH_S(OM, G, 3); break;    \
-      default: WCA_LAUNCH_S(OM, G, 0); break;   \
-    }                                           \
+#define WCA_LAUNCH_S(OM, G, S)                            \
+  do {                                                    \
+    if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
+    else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
+  } while (0)
+#define WCA_LAUNCH(OM, G)                     \
+  do {                                        \
+    switch (a.site) {                         \
+      case 1: WCA_LAUNCH_S(OM, G, 1); break;  \
+      case 2: WCA_LAUNCH_S(OM, G, 2); break;  \
+      case 3: WCA_LAUNCH_S(OM, G, 3); break;  \
+      default: WCA_LAUNCH_S(OM, G, 0); break; \
+    }                                         \
   } while (0)
   if (a.out_mode == 0) {
     if (a.gelu) WCA_LAUNCH(0, true); else WCA_LAUNCH(0, false);
@@ -237,6 +388,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
   }
 #undef WCA_LAUNCH
 #undef WCA_LAUNCH_S
+#undef WCA_LAUNCH_K
   return hipGetLastError();
 }
 
