@@ -45,8 +45,8 @@ def main():
         w = (torch.randn(n, k, device="cuda") * 0.05).half()
         bias = torch.randn(n, device="cuda")
         out = torch.zeros(m, n, device="cuda", dtype=torch.float16 if mode == 0 else torch.float32)
-        for tile in (128, 256):
-            if tile == 256 and m < 2048:
+        for tile in (256, 257, 258):
+            if tile >= 256 and m < 2048:
                 continue
             ms = timeit(lambda: wca._lib.check(lib.wca_test_gemm(eng._h, vp(a), vp(w), vp(bias), vp(out), m, n, k, gelu, mode | (tile << 8))))
             print("gemm %-8s M=%6d N=%6d K=%5d tile=%3d  %8.3f ms  %7.1f TFLOP/s" % (name, m, n, k, tile, ms, 2.0 * m * n * k / ms / 1e9), flush=True)

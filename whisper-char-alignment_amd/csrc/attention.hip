@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float c_log2 = a.scale * LOG2E;
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
 
@@ -94,71 +95,82 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 
     // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r]
     f32x4 st[2][4];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 kf[4];
+    {
+      half8 kf0[4], kf1[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = t * 16 + fr;
-        kf[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((ks * 4 + fg) ^ swz128(r)) << 3));
+        kf0[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((0 + fg) ^ swz128(r)) << 3));
+        kf1[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((4 + fg) ^ swz128(r)) << 3));
       }
+      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-          st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[t], qf[s][ks], st[s][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0[t], qf[s][0], zero, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1[t], qf[s][1], st[s][t], 0, 0, 0);
     }
 
+    // ---- online softmax on the RAW scores (scale > 0 commutes with max); p = exp2(s*c - m*c), c = scale*log2(e).
+    // Masks are only materialised on tiles that need them (last key tile / causal diagonal): wave-uniform branch.
+    const bool tail_tile = (kt * KT + KT > a.nk);
+    const bool diag_tile = CAUSAL && (kt * KT + KT - 1 > q_wave);
     half8 pf[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      float mx = -INFINITY;
+      if (CAPTURE) {
+        if (qrow[s] < a.nq) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int key4 = kt * KT + t * 16 + 4 * fg;
-        f32x4 v = st[s][t] * a.scale;
-        if (CAPTURE) {
-          if (key4 < a.cap_cols && qrow[s] < a.nq) {
-            float* cp = a.cap + (long)b * a.cap_bs + (long)h * a.cap_hs + (long)qrow[s] * a.cap_ld + key4;
-            *reinterpret_cast<f32x4*>(cp) = v;
+          for (int t = 0; t < 4; ++t) {
+            const int key4 = kt * KT + t * 16 + 4 * fg;
+            if (key4 < a.cap_cols) {
+              float* cp = a.cap + (long)b * a.cap_bs + (long)h * a.cap_hs + (long)qrow[s] * a.cap_ld + key4;
+              *reinterpret_cast<f32x4*>(cp) = st[s][t] * a.scale;
+            }
           }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = key4 + r;
-          bool dead = key >= a.nk;
-          if (CAUSAL) dead = dead || (key > qrow[s]);
-          v[r] = dead ? -INFINITY : v[r];
-          mx = fmaxf(mx, v[r]);
-        }
-        st[s][t] = v;
       }
+      if (tail_tile || diag_tile) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * KT + t * 16 + 4 * fg + r;
+            bool dead = key >= a.nk;
+            if (CAUSAL) dead = dead || (key > qrow[s]);
+            st[s][t][r] = dead ? -INFINITY : st[s][t][r];
+          }
+      }
+      float mx = fmaxf(fmaxf(st[s][0][0], st[s][0][1]), fmaxf(st[s][0][2], st[s][0][3]));
+#pragma unroll
+      for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(st[s][t][0], st[s][t][1]), fmaxf(st[s][t][2], st[s][t][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[s], mx);
-      // rows past nq under the causal mask can be fully masked in the first tile: keep them finite
-      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-      const float alpha = exp2f((m_run[s] - m_use) * LOG2E);
+      if (__any(mx > m_run[s])) {  // some row's running max grows: rescale (exactly the textbook update)
+        const float m_new = fmaxf(m_run[s], mx);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run[s] - m_new) * c_log2);
+        l_run[s] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
+        m_run[s] = m_new;
+      }
+      const float mc = (m_run[s] == -INFINITY) ? 0.f : m_run[s] * c_log2;
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f((st[s][t][r] - m_use) * LOG2E);
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc));
           st[s][t][r] = p;
           rs += p;
         }
       rs += __shfl_xor(rs, 16);
       rs += __shfl_xor(rs, 32);
-      l_run[s] = l_run[s] * alpha + rs;
-      m_run[s] = m_new;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
-      // P^T fragments (B operand of O^T = V^T P^T): k-step ks2 covers score tiles 2*ks2, 2*ks2+1
+      l_run[s] += rs;
+      // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         half8 f;

@@ -11,6 +11,8 @@
 // The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
 // W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
 // of one output row: the epilogue stores 32 B (f16) / 64 B (f32) per lane per row.
+#include <type_traits>
+
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -330,15 +332,181 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
   epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined 256 x 256 x 64 kernel (flat A): ONE barrier per K tile, placed between the two K=32
+// halves. At that point every wave has issued and retired all its ds_reads of the current ring slot
+// (fragments of half 1 are fetched while half 0 multiplies), so the barrier is at once
+//   * the WAR guard for refilling this slot with K tile t+2 (DMA issued right after it), and
+//   * the RAW guard for K tile t+1 (each wave's vmcnt(0) precedes the barrier), whose half-0 fragments
+//     are then fetched under the MFMAs of half 1.
+// LDS image: [256 rows][64 f16], 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): depends on
+// r & 15 only, so every fragment address is one per-lane base + an immediate. The W rows are PERMUTED AT DMA
+// TIME (LDS row nt*16 + i of each 64-row block holds W row (i>>2)*16 + nt*4 + (i&3)), which gives each lane
+// 16 contiguous output columns in the epilogue while both operands are read with natural row order.
+// Operands arrive by LDS-DMA through buffer descriptors: rows past M / N read as zero (no clamping), wave w
+// request i covers tile rows i*64 + w*8 .. +7, so ONE per-lane byte offset per operand suffices.
+template <int OUT_MODE, bool GELU, int SITE, bool STAGGER = false>
+__global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);
+  constexpr int TILE256 = 256 * 64;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int ntn = (a.N + 255) / 256;
+  const int ntm = (a.M + 255) / 256;
+  const int nwg = ntm * ntn;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tm = id / ntn, tn = id - tm * ntn;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.A), 0, (int)a.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.W), 0, (int)a.w_bytes, 0x00020000);
+  const int l8 = lane >> 3;
+  const int rho = wave * 8 + l8;                       // LDS row (mod 64) this lane fills
+  const int c0 = (lane & 7) ^ ((rho >> 1) & 7);        // global chunk that lands at chunk position lane & 7
+  const int wsrc_row = ((rho & 15) >> 2) * 16 + (rho >> 4) * 4 + (rho & 3);  // W row held by LDS row rho
+  const int va = ((m0 + rho) * a.lda + c0 * 8) * 2;
+  const int vw = ((n0 + wsrc_row) * a.ldw + c0 * 8) * 2;
+  const int sa64 = 64 * a.lda * 2, sw64 = 64 * a.ldw * 2;
+
+  auto stage = [&](int buf, int k0) {
+    half_t* At = lds + buf * (2 * TILE256);
+    half_t* Wt = At + TILE256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (WCA_LDS void*)(At + (i * 64 + wave * 8) * 64), 16, va + (i * sa64 + k0 * 2), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + wave * 8) * 64), 16, vw + (i * sw64 + k0 * 2), 0, 0, 0);
+    }
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int pos0 = fg ^ ((fr >> 1) & 7);
+  // element offsets of this lane's fragment row 0 for K half 0 / 1 (half 1 = chunk position ^ 4)
+  const int xb0 = (wr * 128 + fr) * 64 + pos0 * 8, xb1 = (wr * 128 + fr) * 64 + (pos0 ^ 4) * 8;
+  const int wb0 = (wc * 64 + fr) * 64 + pos0 * 8, wb1 = (wc * 64 + fr) * 64 + (pos0 ^ 4) * 8;
+
+#define WCA_LOAD_HALF(AT, WT, XB, WB, WF, XF)                                                      \
+  do {                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 4; ++t) WF[t] = *reinterpret_cast<const half8*>((WT) + (WB) + t * 1024); \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) XF[t] = *reinterpret_cast<const half8*>((AT) + (XB) + t * 1024); \
+  } while (0)
+#define WCA_MFMA_GROUP(WF, XF, LO)                                                                 \
+  do {                                                                                             \
+    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt)                                         \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                             \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[nt], XF[mt], acc[mt][nt], 0, 0, 0); \
+  } while (0)
+
+  const int nk = a.K / BK;
+  // The whole main loop + epilogue exists twice; the two wave groups take different copies (one uniform
+  // branch). Group A (waves 0-3) fetches in the MIDDLE of each K half, group B (waves 4-7, the SIMD partners
+  // of 0-3) at the START of each half, so one wave's LDS/DMA issue overlaps its partner's MFMAs instead of
+  // both stalling the matrix pipe together. Dependencies and the barrier sequence are identical.
+  auto body = [&](auto early_tag) {
+    constexpr bool EARLY = decltype(early_tag)::value;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 w0[4], x0[8], w1[4], x1[8];
+    stage(0, 0);
+    if (nk > 1) {
+      stage(1, BK);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+      const int cur = kt & 1;
+      const half_t* At = lds + cur * (2 * TILE256);
+      const half_t* Wt = At + TILE256;
+      // ---- K half 0 (fragments w0/x0 were fetched under the previous tile's half 1)
+      if (EARLY) {
+        WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WCA_MFMA_GROUP(w0, x0, 0);
+        WCA_MFMA_GROUP(w0, x0, 4);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+        WCA_MFMA_GROUP(w0, x0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
+        __builtin_amdgcn_sched_barrier(0);
+        WCA_MFMA_GROUP(w0, x0, 4);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // all ds_reads of slot `cur` are retired; K tile kt+1 (the only DMA in flight) has landed
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---- K half 1; slot `cur` is refilled with tile kt+2, tile kt+1's half-0 fragments are fetched
+      if (EARLY) {
+        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+        if (kt + 1 < nk) {
+          const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
+          WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WCA_MFMA_GROUP(w1, x1, 0);
+        WCA_MFMA_GROUP(w1, x1, 4);
+        __builtin_amdgcn_s_setprio(0);
+      } else {
+        __builtin_amdgcn_s_setprio(1);
+        WCA_MFMA_GROUP(w1, x1, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+        if (kt + 1 < nk) {
+          const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
+          WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        WCA_MFMA_GROUP(w1, x1, 4);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
+  };
+  if (STAGGER && wr == 1) {
+    body(std::true_type{});
+  } else {
+    body(std::false_type{});
+  }
+#undef WCA_MFMA_GROUP
+#undef WCA_LOAD_HALF
+}
+
 }  // namespace
 
-hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
+hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
+  GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || (a.K % BK) != 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
   // tile choice: the 256^2 kernel runs one workgroup per CU, so it needs about a full wave of 256 workgroups
   const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const bool big = (a.force_tile == 256) || (a.force_tile == 0 && tiles256 >= 192);
+  const size_t a_need = ((size_t)(a.M - 1) * a.lda + a.K) * sizeof(half_t), w_need = ((size_t)(a.N - 1) * a.ldw + a.K) * sizeof(half_t);
+  const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
+  if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
+  if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
+  const bool staggered = (a.force_tile == 258) && can_buf;  // A/B experiment: no gain measured, kept for tests
+  const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || staggered) || (a.force_tile == 0 && tiles256 >= 192);
+  const bool pipelined = want_big && can_buf && a.force_tile != 256;
+  const bool big = want_big;
   dim3 grid, block;
   size_t shmem;
   if (big) {
@@ -362,9 +530,22 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
     }                                                                                             \
     hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
+#define WCA_LAUNCH_K2(KERN, OM, G, S, ST)                                                         \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, ST>),       \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+      if (e != hipSuccess) return e;                                                              \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((KERN<OM, G, S, ST>), grid, block, shmem, s, a);                           \
+  } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
+    if (staggered) WCA_LAUNCH_K2(gemm256p_f16_kernel, OM, G, S, true); \
+    else if (pipelined) WCA_LAUNCH_K2(gemm256p_f16_kernel, OM, G, S, false); \
+    else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
   } while (0)
 #define WCA_LAUNCH(OM, G)                     \
@@ -389,6 +570,7 @@ hipError_t launch_gemm(const GemmArgs& a, hipStream_t s) {
 #undef WCA_LAUNCH
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
+#undef WCA_LAUNCH_K2
   return hipGetLastError();
 }
 
