@@ -35,9 +35,9 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--model", type=str, default="medium")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chars", type=int, default=64)
@@ -113,7 +113,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("WCA_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    if os.environ.get("WCA_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -161,9 +167,10 @@ def main():
         if args.stages:
             stage_acc += np.array(model.last_stage_ms())
     # collate: one all-gather of the packed per-utterance jump frames (the only collective on the path)
-    packed = torch.from_numpy(np.stack(results).astype(np.int32)).to(device)
+    coll_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
+    packed = torch.from_numpy(np.stack(results).astype(np.int32)).to(coll_dev)
     if dist is not None:
-        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=device)
+        gathered = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=coll_dev)
         dist.all_gather_into_tensor(gathered, packed)
         _ = gathered.cpu()
     torch.cuda.synchronize()
@@ -172,7 +179,7 @@ def main():
     elapsed = time.perf_counter() - t0
     model.set_profiling(False)
     if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -28,7 +28,7 @@ def eng(wca):
 # ------------------------------------------------------------------------------- GEMM
 @pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1500, 1152, 384), (77, 130, 64), (128, 128, 64), (3000, 384, 256)])
 @pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
-@pytest.mark.parametrize("tile", [128, 256, 257, 258])
+@pytest.mark.parametrize("tile", [128, 256, 257])
 def test_gemm(eng, lib, wca, M, N, K, mode, tile):
     g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
     a = (torch.randn(M, K, generator=g) * 0.5).half()
@@ -68,7 +68,7 @@ def test_gemm_256_tile_long_k_and_tails(eng, lib, wca, M, N, K):
     ad, wd = a.cuda(), w.cuda()
     for _ in range(3):  # repeated launches: a stale-ring race would show up as run-to-run differences
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-        for tile in (256, 257, 258):
+        for tile in (256, 257):
             out.fill_(float('nan'))
             wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), None, _vp(out), M, N, K, 0, 1 | (tile << 8)))
             torch.cuda.synchronize()

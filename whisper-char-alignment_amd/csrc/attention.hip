@@ -81,6 +81,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float c_log2 = a.scale * LOG2E;
+  half8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
 
@@ -144,9 +147,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             st[s][t][r] = dead ? -INFINITY : st[s][t][r];
           }
       }
-      float mx = fmaxf(fmaxf(st[s][0][0], st[s][0][1]), fmaxf(st[s][0][2], st[s][0][3]));
+      float mx = st[s][0][0];
 #pragma unroll
-      for (int t = 1; t < 4; ++t) mx = fmaxf(mx, fmaxf(fmaxf(st[s][t][0], st[s][t][1]), fmaxf(st[s][t][2], st[s][t][3])));
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) mx = fmaxf(fmaxf(mx, st[s][t][r]), st[s][t][r + 1]);  // -> v_max3_f32
       mx = fmaxf(mx, __shfl_xor(mx, 16));
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       if (__any(mx > m_run[s])) {  // some row's running max grows: rescale (exactly the textbook update)
@@ -158,18 +163,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         m_run[s] = m_new;
       }
       const float mc = (m_run[s] == -INFINITY) ? 0.f : m_run[s] * c_log2;
-      float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc));
-          st[s][t][r] = p;
-          rs += p;
-        }
-      rs += __shfl_xor(rs, 16);
-      rs += __shfl_xor(rs, 32);
-      l_run[s] += rs;
+        for (int r = 0; r < 4; ++r) st[s][t][r] = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc));
       // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
@@ -181,6 +178,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         }
         pf[s][k2] = f;
       }
+      // row sums on the matrix pipe: D[i][q] = sum_k 1 * P^T[k][q] for every i, i.e. the sum over the tile's 64
+      // keys of exactly the f16-rounded probabilities that enter P.V (no VALU adds, no cross-lane step)
+      f32x4 rsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      rsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][1], rsum, 0, 0, 0);
+      l_run[s] += rsum[0];
     }
 
     // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr],

@@ -11,8 +11,6 @@
 // The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
 // W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
 // of one output row: the epilogue stores 32 B (f16) / 64 B (f32) per lane per row.
-#include <type_traits>
-
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
 // 16 contiguous output columns in the epilogue while both operands are read with natural row order.
 // Operands arrive by LDS-DMA through buffer descriptors: rows past M / N read as zero (no clamping), wave w
 // request i covers tile rows i*64 + w*8 .. +7, so ONE per-lane byte offset per operand suffices.
-template <int OUT_MODE, bool GELU, int SITE, bool STAGGER = false>
+template <int OUT_MODE, bool GELU, int SITE>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -401,12 +399,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   } while (0)
 
   const int nk = a.K / BK;
-  // The whole main loop + epilogue exists twice; the two wave groups take different copies (one uniform
-  // branch). Group A (waves 0-3) fetches in the MIDDLE of each K half, group B (waves 4-7, the SIMD partners
-  // of 0-3) at the START of each half, so one wave's LDS/DMA issue overlaps its partner's MFMAs instead of
-  // both stalling the matrix pipe together. Dependencies and the barrier sequence are identical.
-  auto body = [&](auto early_tag) {
-    constexpr bool EARLY = decltype(early_tag)::value;
+  // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
+  //  fetch/MFMA orders to break SIMD-partner lockstep; a software L2 prefetch two tiles ahead of the DMA.)
+  {
     f32x4 acc[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -429,62 +424,35 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       const half_t* At = lds + cur * (2 * TILE256);
       const half_t* Wt = At + TILE256;
       // ---- K half 0 (fragments w0/x0 were fetched under the previous tile's half 1)
-      if (EARLY) {
-        WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        WCA_MFMA_GROUP(w0, x0, 0);
-        WCA_MFMA_GROUP(w0, x0, 4);
-        __builtin_amdgcn_s_setprio(0);
-      } else {
-        __builtin_amdgcn_s_setprio(1);
-        WCA_MFMA_GROUP(w0, x0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
-        __builtin_amdgcn_sched_barrier(0);
-        WCA_MFMA_GROUP(w0, x0, 4);
-        __builtin_amdgcn_s_setprio(0);
-      }
+      __builtin_amdgcn_s_setprio(1);
+      WCA_MFMA_GROUP(w0, x0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      WCA_MFMA_GROUP(w0, x0, 4);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
       // all ds_reads of slot `cur` are retired; K tile kt+1 (the only DMA in flight) has landed
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       // ---- K half 1; slot `cur` is refilled with tile kt+2, tile kt+1's half-0 fragments are fetched
-      if (EARLY) {
-        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
-        if (kt + 1 < nk) {
-          const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
-          WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        WCA_MFMA_GROUP(w1, x1, 0);
-        WCA_MFMA_GROUP(w1, x1, 4);
-        __builtin_amdgcn_s_setprio(0);
-      } else {
-        __builtin_amdgcn_s_setprio(1);
-        WCA_MFMA_GROUP(w1, x1, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
-        if (kt + 1 < nk) {
-          const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
-          WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-        WCA_MFMA_GROUP(w1, x1, 4);
-        __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_setprio(1);
+      WCA_MFMA_GROUP(w1, x1, 0);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
+      if (kt + 1 < nk) {
+        const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
+        WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      WCA_MFMA_GROUP(w1, x1, 4);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
     }
     epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
-  };
-  if (STAGGER && wr == 1) {
-    body(std::true_type{});
-  } else {
-    body(std::false_type{});
   }
 #undef WCA_MFMA_GROUP
 #undef WCA_LOAD_HALF
@@ -503,8 +471,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
   if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
   if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
-  const bool staggered = (a.force_tile == 258) && can_buf;  // A/B experiment: no gain measured, kept for tests
-  const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || staggered) || (a.force_tile == 0 && tiles256 >= 192);
+  const bool want_big = (a.force_tile == 256 || a.force_tile == 257) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
   dim3 grid, block;
@@ -530,21 +497,9 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }                                                                                             \
     hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
-#define WCA_LAUNCH_K2(KERN, OM, G, S, ST)                                                         \
-  do {                                                                                            \
-    static bool attr_set = false;                                                                 \
-    if (!attr_set) {                                                                              \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, ST>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
-      if (e != hipSuccess) return e;                                                              \
-      attr_set = true;                                                                            \
-    }                                                                                             \
-    hipLaunchKernelGGL((KERN<OM, G, S, ST>), grid, block, shmem, s, a);                           \
-  } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (staggered) WCA_LAUNCH_K2(gemm256p_f16_kernel, OM, G, S, true); \
-    else if (pipelined) WCA_LAUNCH_K2(gemm256p_f16_kernel, OM, G, S, false); \
+    if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
   } while (0)
@@ -570,7 +525,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #undef WCA_LAUNCH
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
-#undef WCA_LAUNCH_K2
   return hipGetLastError();
 }
 
