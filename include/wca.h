@@ -170,6 +170,10 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
  * 2 f32 accumulate; out_mode >> 8: force the tile shape (0 auto, 128, 256). */
 int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                   int N, int K, int gelu, int out_mode);
+/* diagnostic build of the pipelined 256x256 GEMM that records s_memtime stamps per K tile into dbg_dev
+ * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product */
+int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
+                          int out_mode, unsigned long long* dbg_dev);
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL */
 int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
                        float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);

@@ -2,6 +2,7 @@
 cross-attention logits, post-processing, DTW) against the CPU oracle on seeded tiny-dims models, and the
 fused wca_align_batch path against the step-by-step drop-in API."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -129,3 +130,30 @@ def test_too_long_is_rejected(wca, setup):
         tm.get_attentions(mel, torch.zeros(449, dtype=torch.int64).cuda(), model, tok, 100)
     with pytest.raises(wca._lib.TooLongError):
         tm.get_attentions(mel, torch.zeros(10, dtype=torch.int64).cuda(), model, tok, 1501)
+
+
+def test_north_star_config_parity_medium_dims(wca):
+    """whisper-medium dimensions (seeded random weights), 10 s audio, 64-char text, topk=10, medfilt 3:
+    f16-MFMA engine vs the fp32 CPU oracle. Word start/end times must be within one 20 ms frame."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 1, 160000, 64)
+    assert len(tokens) == 69
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    w, logits = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
+    words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=10)
+    rw, rlogits = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, 500, 3, 1.0)
+    rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
+    assert tuple(w.shape) == (24, 16, 69, 500)
+    assert (w.cpu() - rw).abs().max().item() < 1e-2          # measured 3e-3 (peaky maps, values up to 0.5)
+    assert ((logits.cpu() - rlogits).abs().max() / rlogits.abs().max()).item() < 5e-3   # measured 8e-4
+    assert words == rwords
+    assert np.all(np.abs(st - rst) <= 0.0201) and np.all(np.abs(en - ren) <= 0.0201)
+    assert len(set(lh for _, lh, _ in scores) & set(lh for _, lh, _ in rscores)) >= 9
+    del model

@@ -61,6 +61,7 @@ SIGNATURES = {
     "wca_align_batch_enqueue": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts)]),
     "wca_align_batch_fetch": (_i, [_vp, _i, _i, _i, _pi32, _pi32]),
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "wca_test_encoder": (_i, [_vp, _vp, _i, _vp]),

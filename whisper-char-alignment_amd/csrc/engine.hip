@@ -1301,6 +1301,26 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   return WCA_OK;
 }
 
+int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, int M, int N, int K, int out_mode, unsigned long long* dbg_dev) {
+  if (!e || !dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  GemmArgs g{};
+  g.A = (const half_t*)a;
+  g.lda = K;
+  g.W = (const half_t*)w;
+  g.ldw = K;
+  g.C = c;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.out_mode = out_mode;
+  g.force_tile = 257;
+  g.dbg = dbg_dev;
+  HIPCHK(launch_gemm(g, e->stream));
+  return WCA_OK;
+}
+
 int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
                        int B, int H, int nq, int nk, int causal) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");

@@ -330,6 +330,90 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
   epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
 }
 
+// Epilogue of the pipelined 256 x 256 kernel (column maps documented at `wsrc_row` there): every store
+// instruction writes 64 contiguous bytes per output row (4 lanes x 16 B).
+template <int OUT_MODE, bool GELU>
+__device__ __forceinline__ void epilogue_wide(const GemmArgs& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg) {
+  // column of value (nt, r = 0) relative to nbase
+  int col[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) col[nt] = (OUT_MODE == 0) ? ((nt >> 1) * 32 + fg * 8 + (nt & 1) * 4) : (nt * 16 + fg * 4);
+  float bv[16];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = nbase + col[nt] + r;
+      bv[nt * 4 + r] = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
+    }
+  const bool full_n = (nbase + 64 <= a.N);
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = mbase + mt * 16 + fr;
+    float v[16];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
+    if (m >= a.M) continue;
+    if (GELU) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+    }
+    if (a.pos != nullptr) {
+      const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nbase;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (nbase + col[nt] + r < a.N) v[nt * 4 + r] += pp[col[nt] + r];
+    }
+    long coff;
+    if (a.c_rows_per_batch > 0) {
+      const int b = m / a.c_rows_per_batch;
+      const int t = m - b * a.c_rows_per_batch;
+      coff = (long)b * a.c_batch_stride + (long)t * a.ldc;
+    } else {
+      coff = (long)m * a.ldc;
+    }
+    if (OUT_MODE == 0) {
+      half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nbase;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 8) & 15) == 0)) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[hh * 8 + j];
+          *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nbase + col[nt] + r < a.N) cp[col[nt] + r] = (half_t)v[nt * 4 + r];
+      }
+    } else {
+      float* cp = reinterpret_cast<float*>(a.C) + coff + nbase;
+      if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 4) & 15) == 0)) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          f32x4* c4 = reinterpret_cast<f32x4*>(cp + col[nt]);
+          f32x4 o = f32x4{v[nt * 4 + 0], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]};
+          if (OUT_MODE == 2) o += *c4;
+          *c4 = o;
+        }
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (nbase + col[nt] + r < a.N) cp[col[nt] + r] = (OUT_MODE == 2) ? cp[col[nt] + r] + v[nt * 4 + r] : v[nt * 4 + r];
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined 256 x 256 x 64 kernel (flat A): ONE barrier per K tile, placed between the two K=32
 // halves. At that point every wave has issued and retired all its ds_reads of the current ring slot
@@ -339,11 +423,11 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
 //     are then fetched under the MFMAs of half 1.
 // LDS image: [256 rows][64 f16], 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): depends on
 // r & 15 only, so every fragment address is one per-lane base + an immediate. The W rows are PERMUTED AT DMA
-// TIME (LDS row nt*16 + i of each 64-row block holds W row (i>>2)*16 + nt*4 + (i&3)), which gives each lane
-// 16 contiguous output columns in the epilogue while both operands are read with natural row order.
+// TIME (which W row lands in LDS row nt*16 + i of each 64-row block depends on the output type, see `wsrc_row`),
+// so that the epilogue's stores are contiguous while both operands are read with natural row order.
 // Operands arrive by LDS-DMA through buffer descriptors: rows past M / N read as zero (no clamping), wave w
 // request i covers tile rows i*64 + w*8 .. +7, so ONE per-lane byte offset per operand suffices.
-template <int OUT_MODE, bool GELU, int SITE>
+template <int OUT_MODE, bool GELU, int SITE, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -365,19 +449,29 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   const int l8 = lane >> 3;
   const int rho = wave * 8 + l8;                       // LDS row (mod 64) this lane fills
   const int c0 = (lane & 7) ^ ((rho >> 1) & 7);        // global chunk that lands at chunk position lane & 7
-  const int wsrc_row = ((rho & 15) >> 2) * 16 + (rho >> 4) * 4 + (rho & 3);  // W row held by LDS row rho
+  // W row held by LDS row rho = nt*16 + i (i = MFMA row of n-tile nt). Chosen per output type so that in the
+  // epilogue the four lanes (fg = 0..3) that share an output row write 64 CONTIGUOUS bytes per store instruction:
+  //   f16 out: lane fg owns columns fg*8 .. +7 and 32 + fg*8 .. +7   -> n = (nt>>1)*32 + (i>>2)*8 + (nt&1)*4 + (i&3)
+  //   f32 out: lane fg owns columns nt*16 + fg*4 .. +3 (natural)      -> n = nt*16 + i
+  const int nt_r = rho >> 4, i_r = rho & 15;
+  const int wsrc_row = (OUT_MODE == 0) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
   const int va = ((m0 + rho) * a.lda + c0 * 8) * 2;
   const int vw = ((n0 + wsrc_row) * a.ldw + c0 * 8) * 2;
   const int sa64 = 64 * a.lda * 2, sw64 = 64 * a.ldw * 2;
 
-  auto stage = [&](int buf, int k0) {
+  // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each
+  auto stage_one = [&](int buf, int k0, int g) {
     half_t* At = lds + buf * (2 * TILE256);
     half_t* Wt = At + TILE256;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    const int i = g >> 1;
+    if ((g & 1) == 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (WCA_LDS void*)(At + (i * 64 + wave * 8) * 64), 16, va + (i * sa64 + k0 * 2), 0, 0, 0);
+    else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + wave * 8) * 64), 16, vw + (i * sw64 + k0 * 2), 0, 0, 0);
-    }
+  };
+  auto stage = [&](int buf, int k0) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) stage_one(buf, k0, g);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -419,40 +513,76 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     asm volatile("" ::: "memory");
     WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
 
+#define WCA_STAMP(IDX)                                                                      \
+  do {                                                                                     \
+    if (STAMP) {                                                                           \
+      unsigned long long t_;                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      if (lane == 0 && blockIdx.x < 4) a.dbg[((blockIdx.x * 8 + wave) * 64 + kt) * 8 + (IDX)] = t_; \
+    }                                                                                      \
+  } while (0)
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       const half_t* At = lds + cur * (2 * TILE256);
       const half_t* Wt = At + TILE256;
-      // ---- K half 0 (fragments w0/x0 were fetched under the previous tile's half 1)
-      __builtin_amdgcn_s_setprio(1);
-      WCA_MFMA_GROUP(w0, x0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      WCA_LOAD_HALF(At, Wt, xb1, wb1, w1, x1);
-      __builtin_amdgcn_sched_barrier(0);
-      WCA_MFMA_GROUP(w0, x0, 4);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+      WCA_STAMP(0);
+      // ---- K half 0 (fragments w0/x0 were fetched under the previous tile's half 1). The 12 fragment reads of
+      // half 1 are issued two at a time between groups of 4 MFMAs.
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[g], acc[g][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (g < 2) {
+          w1[2 * g] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g) * 1024);
+          w1[2 * g + 1] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g + 1) * 1024);
+        } else if (g < 6) {
+          x1[2 * (g - 2)] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2)) * 1024);
+          x1[2 * (g - 2) + 1] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2) + 1) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      WCA_STAMP(1);
       // all ds_reads of slot `cur` are retired; K tile kt+1 (the only DMA in flight) has landed
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // ---- K half 1; slot `cur` is refilled with tile kt+2, tile kt+1's half-0 fragments are fetched
-      __builtin_amdgcn_s_setprio(1);
-      WCA_MFMA_GROUP(w1, x1, 0);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (kt + 2 < nk) stage(cur, (kt + 2) * BK);
-      if (kt + 1 < nk) {
-        const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
-        WCA_LOAD_HALF(An, An + TILE256, xb0, wb0, w0, x0);
+      WCA_STAMP(3);
+      // ---- K half 1. Slot `cur` is refilled with tile kt+2 and tile kt+1's half-0 fragments are fetched, ONE
+      // DMA request and up to two ds_reads per group of 4 MFMAs: 64 back-to-back requests per CU right after the
+      // barrier serialise in the memory pipe and delay the MFMAs of the waves that issue last (measured with
+      // s_memtime stamps: ~1000 cycles of barrier skew per K tile).
+      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
+      const half_t* Wn = An + TILE256;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more2) stage_one(cur, (kt + 2) * BK, g);
+        if (more1) {
+          if (g < 2) {
+            w0[2 * g] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g) * 1024);
+            w0[2 * g + 1] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g + 1) * 1024);
+          } else if (g < 6) {
+            x0[2 * (g - 2)] = *reinterpret_cast<const half8*>(An + xb0 + (2 * (g - 2)) * 1024);
+            x0[2 * (g - 2) + 1] = *reinterpret_cast<const half8*>(An + xb0 + (2 * (g - 2) + 1) * 1024);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-      WCA_MFMA_GROUP(w1, x1, 4);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_sched_barrier(0);
+      WCA_STAMP(4);
     }
-    epilogue<OUT_MODE, GELU, 8>(a, acc, m0 + wr * 128, n0 + wc * 64 + fg * 16, fr);
+#undef WCA_STAMP
+    epilogue_wide<OUT_MODE, GELU>(a, acc, m0 + wr * 128, n0 + wc * 64, fr, fg);
   }
 #undef WCA_MFMA_GROUP
 #undef WCA_LOAD_HALF
@@ -497,9 +627,17 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }                                                                                             \
     hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
+#define WCA_LAUNCH_K4(KERN, OM, G, S, ST)                                                         \
+  do {                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, ST>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
+    if (e != hipSuccess) return e;                                                                \
+    hipLaunchKernelGGL((KERN<OM, G, S, ST>), grid, block, shmem, s, a);                           \
+  } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
+    if (pipelined && a.dbg) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, S, true); \
+    else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
   } while (0)
@@ -525,6 +663,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #undef WCA_LAUNCH
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
+#undef WCA_LAUNCH_K4
   return hipGetLastError();
 }
 

@@ -29,6 +29,7 @@ struct GemmArgs {
   int gelu;                // apply exact (erf) GELU after bias
   int out_mode;            // 0: store f16, 1: store f32, 2: f32 accumulate (C += result)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
+  unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
   int site;                // 0 generic, 1 encoder block, 2 decoder, 3 conv stem / cross-KV / logits: selects a distinct
                            // kernel symbol per call site so rocprofv3 --stats separates the shapes
