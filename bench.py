@@ -102,6 +102,21 @@ def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod):
                       "PyTorch-CPU fp32 forward + oracle post-processing, %.2f s/utt" % (len(times), per)}
 
 
+def measured_traffic(args, dims):
+    """L2<->fabric bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded under profiles/
+    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); only quoted when this
+    run uses the configuration those passes were collected on, else null."""
+    path = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec["M"] == args.batch * 1500 and rec["N"] == 4 * dims.n_audio_state and rec["K"] == dims.n_audio_state:
+            return rec["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -195,10 +210,10 @@ def main():
                                    "%d-char teacher text, char align, aggr=topk topk=%d medfilt_width=%d" %
                                    (args.model, args.seconds, args.chars, args.topk, args.medfilt_width),
                        "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel<0,true,1> (encoder MLP fc1, M=%d N=%d K=%d)" %
+            "roofline": {"bound": "mfma", "kernel": "gemm256p_f16_kernel<0, true, 1, false> (encoder MLP fc1, M=%d N=%d K=%d)" %
                                                      (args.batch * 1500, 4 * dims.n_audio_state, dims.n_audio_state),
                          "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": measured_traffic(args, dims),
                          "avg_launch_ms": avg_ms, "launches_timed": dom_n},
         }
         if args.stages:

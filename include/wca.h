@@ -177,6 +177,9 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f1
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL */
 int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
                        float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
+/* diagnostic build with s_memtime stamps per key tile ([4 blocks][4 waves][32 tiles][8] u64); tools/attn_stamps.py */
+int wca_test_attention_stamped(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev, int B, int H,
+                               int nq, int nk, unsigned long long* dbg_dev);
 int wca_test_layernorm(wca_engine* e, const float* x_dev, const float* g_dev, const float* b_dev, void* out_f16_dev,
                        int rows, int d);
 /* encoder only: mel_dev [batch][n_mels][3000] f32 -> xa_out_dev [batch][1500][d] f32 (ln_post output) */

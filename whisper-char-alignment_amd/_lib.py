@@ -63,6 +63,7 @@ SIGNATURES = {
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "wca_test_attention_stamped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "wca_test_encoder": (_i, [_vp, _vp, _i, _vp]),
     "wca_last_stage_ms": (_i, [_vp, _pf]),

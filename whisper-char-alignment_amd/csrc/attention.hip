@@ -5,7 +5,7 @@
 //     exactly what the reference's forward hooks collect (timing.py:50-55, outs[-1]).
 //
 // Structure: 256-thread workgroup = 4 waves, each wave owns 32 query rows (two 16-row subtiles);
-// 64-key K/V tiles are streamed HBM -> LDS with LDS-DMA (double buffered). Scores are computed
+// 64-key K/V tiles are streamed HBM -> LDS with LDS-DMA (ring of 3, two tiles ahead). Scores are computed
 // TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_f16) so a query row lives on one lane column and
 // the online-softmax statistics are lane-local (+2 cross-lane steps). P^T feeds the second MFMA
 // (O^T = V^T P^T) straight from registers; V^T fragments come from ds_read_b64_tr_b16.
@@ -20,12 +20,24 @@ constexpr int KT = 64;               // keys per tile
 constexpr int TILE = 64 * 64;        // f16 elements of one K or V tile
 constexpr float LOG2E = 1.4426950408889634f;
 
+// max over the lanes {l, l^16} / {l, l^32} without LDS: the swap returns {own, partner} in some order
+__device__ __forceinline__ float xor16_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 __device__ __forceinline__ half4 tr_read4(const half_t* p) {
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WCA_LDS s16x4*)(p));
   return __builtin_bit_cast(half4, r);
 }
 
-template <bool CAUSAL, bool CAPTURE>
+template <bool CAUSAL, bool CAPTURE, bool STAMP = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);  // [buf][K tile | V tile]
@@ -33,8 +45,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q_blk = blockIdx.x * 128;
+  // 1-D grid, XCD-aware: logical id = ((b*H + h) * n_qt + qt); the bijective remap gives every XCD a contiguous
+  // range of logical ids, so all query tiles of one (batch, head) run on ONE XCD and share its K/V in that L2.
+  const int n_qt = (a.nq + 127) / 128;
+  const int lid = xcd_remap(blockIdx.x, n_qt * a.H * a.B);
+  const int bh = lid / n_qt;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q_blk = (lid - bh * n_qt) * 128;
   const int q_wave = q_blk + wave * 32;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane holds Q[q = fr][dd = ks*32 + 8*fg + j]
@@ -87,14 +104,42 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   float m_run[2] = {-INFINITY, -INFINITY};
   float l_run[2] = {0.f, 0.f};
 
+  // K/V ring of 3 tiles, LDS-DMA two tiles ahead, counted vmcnt, ONE raw barrier per key tile: at the top of
+  // tile kt every wave has waited for its own requests of tile kt (the 4 of tile kt+1 may stay in flight), so
+  // the barrier publishes tile kt (RAW) and also proves that everyone is done with tile kt-1, whose slot is
+  // refilled with tile kt+2 right after it (WAR).
   stage(0, 0);
-  wait_vm0();
-  __syncthreads();
-  int cur = 0;
+  if (nkt > 1) stage(1, 1);
+  int slot = 0;
+#define WCA_STAMP(IDX)                                                                      \
+  do {                                                                                     \
+    if (STAMP) {                                                                           \
+      unsigned long long t_;                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      if (lane == 0 && blockIdx.x < 4 && kt < 32) a.dbg[((blockIdx.x * 4 + wave) * 32 + kt) * 8 + (IDX)] = t_; \
+    }                                                                                      \
+  } while (0)
   for (int kt = 0; kt < nkt; ++kt) {
-    if (kt + 1 < nkt) stage(cur ^ 1, kt + 1);
-    const half_t* Kt = lds + cur * (2 * TILE);
+    WCA_STAMP(0);
+    if (kt + 1 < nkt) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    WCA_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WCA_STAMP(2);
+    if (kt + 2 < nkt) {
+      int nslot = slot + 2;
+      nslot = nslot >= 3 ? nslot - 3 : nslot;
+      stage(nslot, kt + 2);
+    }
+    const half_t* Kt = lds + slot * (2 * TILE);
     const half_t* Vt = Kt + TILE;
+    slot = (slot == 2) ? 0 : slot + 1;
 
     // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r]
     f32x4 st[2][4];
@@ -116,15 +161,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf1[t], qf[s][1], st[s][t], 0, 0, 0);
     }
+    WCA_STAMP(3);
 
     // ---- online softmax on the RAW scores (scale > 0 commutes with max); p = exp2(s*c - m*c), c = scale*log2(e).
-    // Masks are only materialised on tiles that need them (last key tile / causal diagonal): wave-uniform branch.
-    const bool tail_tile = (kt * KT + KT > a.nk);
-    const bool diag_tile = CAUSAL && (kt * KT + KT - 1 > q_wave);
-    half8 pf[2][2];
+    // Both 16-row subtiles advance together (one combined rescale branch) so their dependency chains interleave.
+    if (CAPTURE) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      if (CAPTURE) {
+      for (int s = 0; s < 2; ++s) {
         if (qrow[s] < a.nq) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) {
@@ -136,7 +179,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
           }
         }
       }
-      if (tail_tile || diag_tile) {
+    }
+    // masks are only materialised on tiles that need them (last key tile / causal diagonal): wave-uniform branch
+    const bool tail_tile = (kt * KT + KT > a.nk);
+    const bool diag_tile = CAUSAL && (kt * KT + KT - 1 > q_wave);
+    if (tail_tile || diag_tile) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -146,28 +195,45 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
             if (CAUSAL) dead = dead || (key > qrow[s]);
             st[s][t][r] = dead ? -INFINITY : st[s][t][r];
           }
-      }
-      float mx = st[s][0][0];
+    }
+    float mx[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float m = st[s][0][0];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) mx = fmaxf(fmaxf(mx, st[s][t][r]), st[s][t][r + 1]);  // -> v_max3_f32
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (__any(mx > m_run[s])) {  // some row's running max grows: rescale (exactly the textbook update)
-        const float m_new = fmaxf(m_run[s], mx);
+        for (int r = 0; r < 4; r += 2) m = fmaxf(fmaxf(m, st[s][t][r]), st[s][t][r + 1]);
+      mx[s] = m;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mx[s] = xor16_max(mx[s]);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mx[s] = xor32_max(mx[s]);
+    if (__any((mx[0] > m_run[0]) || (mx[1] > m_run[1]))) {  // some row's running max grows: textbook rescale
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float m_new = fmaxf(m_run[s], mx[s]);
         const float alpha = (m_new == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run[s] - m_new) * c_log2);
         l_run[s] *= alpha;
 #pragma unroll
         for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
         m_run[s] = m_new;
       }
-      const float mc = (m_run[s] == -INFINITY) ? 0.f : m_run[s] * c_log2;
+    }
+    float mc[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) mc[s] = (m_run[s] == -INFINITY) ? 0.f : m_run[s] * c_log2;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) st[s][t][r] = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc));
-      // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
+        for (int r = 0; r < 4; ++r) st[s][t][r] = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc[s]));
+    // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
+    half8 pf[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
         half8 f;
@@ -178,12 +244,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         }
         pf[s][k2] = f;
       }
-      // row sums on the matrix pipe: D[i][q] = sum_k 1 * P^T[k][q] for every i, i.e. the sum over the tile's 64
-      // keys of exactly the f16-rounded probabilities that enter P.V (no VALU adds, no cross-lane step)
+    // row sums on the matrix pipe: D[i][q] = sum_k 1 * P^T[k][q] for every i, i.e. the sum over the tile's 64
+    // keys of exactly the f16-rounded probabilities that enter P.V (no VALU adds, no cross-lane step)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
       f32x4 rsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
       rsum = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][1], rsum, 0, 0, 0);
       l_run[s] += rsum[0];
     }
+    WCA_STAMP(4);
 
     // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr],
     // k order matches pf: j<4 -> key (2*k2)*16 + 4*fg + j, j>=4 -> key (2*k2+1)*16 + 4*fg + (j-4).
@@ -211,10 +280,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         }
       }
     }
-    wait_vm0();
-    __syncthreads();
-    cur ^= 1;
+    WCA_STAMP(5);
   }
+#undef WCA_STAMP
 
   // ---- epilogue: ot[s][dt][r] = O[q = fr][d = dt*16 + 4*fg + r]
 #pragma unroll
@@ -239,9 +307,13 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.nk <= 0) return hipErrorInvalidValue;
   if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;
   if (a.cap != nullptr && ((a.cap_ld % 4) != 0 || a.cap_ld < ((a.cap_cols + 3) & ~3))) return hipErrorInvalidValue;
-  dim3 grid((a.nq + 127) / 128, a.H, a.B), block(256);
-  const size_t shmem = 2 * 2 * TILE * sizeof(half_t);  // 32 KiB
+  dim3 grid(((a.nq + 127) / 128) * a.H * a.B), block(256);
+  const size_t shmem = 3 * 2 * TILE * sizeof(half_t);  // 48 KiB
   const bool cap = a.cap != nullptr && a.cap_cols > 0;
+  if (a.dbg) {
+    hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, block, shmem, s, a);
+    return hipGetLastError();
+  }
   if (a.causal) {
     if (cap) hipLaunchKernelGGL((attn_kernel<true, true>), grid, block, shmem, s, a);
     else hipLaunchKernelGGL((attn_kernel<true, false>), grid, block, shmem, s, a);

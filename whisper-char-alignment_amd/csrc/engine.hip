@@ -1321,8 +1321,11 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, 
   return WCA_OK;
 }
 
-int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
-                       int B, int H, int nq, int nk, int causal) {
+int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nk,
+                               unsigned long long* dbg_dev);
+
+static int test_attention_impl(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
+                               int B, int H, int nq, int nk, int causal, unsigned long long* dbg) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   HIPCHK(hipSetDevice(e->device));
   AttnArgs a{};
@@ -1350,8 +1353,20 @@ int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* 
   a.B = B;
   a.scale = 0.125f;
   a.causal = causal;
+  a.dbg = dbg;
   HIPCHK(launch_attention(a, e->stream));
   return WCA_OK;
+}
+
+int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
+                       int B, int H, int nq, int nk, int causal) {
+  return test_attention_impl(e, q, k, v, o, cap_dev, cap_ld, cap_cols, B, H, nq, nk, causal, nullptr);
+}
+
+int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nk,
+                               unsigned long long* dbg_dev) {
+  if (!dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
+  return test_attention_impl(e, q, k, v, o, nullptr, 0, 0, B, H, nq, nk, 0, dbg_dev);
 }
 
 int wca_test_layernorm(wca_engine* e, const float* x, const float* g, const float* b, void* out, int rows, int d) {

@@ -50,6 +50,7 @@ struct AttnArgs {
   int nq, nk, H, B;
   float scale;                             // applied to q.k (head_dim^-0.5)
   int causal;
+  unsigned long long* dbg;                 // diagnostic builds only (s_memtime stamps)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
