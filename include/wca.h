@@ -157,8 +157,9 @@ int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, con
                     const int32_t* max_frames_host, int batch, const wca_align_opts* opts, int32_t* jump_frame_host,
                     int32_t* sel_idx_host);
 
-/* Same pipeline, but only enqueues the work on the engine stream (no host sync, results stay in the
- * engine's pinned staging buffers until wca_align_batch_fetch). Used by bench.py to time with HIP events. */
+/* Same pipeline, but only enqueues the work on the engine stream (no host sync; results stay in the engine's
+ * pinned staging ring until wca_align_batch_fetch). Up to TWO batches may be in flight: _fetch returns the
+ * OLDEST pending one (waiting on its HIP event only), so the host can post-process batch i while batch i+1 runs. */
 int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
                             const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host,
                             const int32_t* max_frames_host, int batch, const wca_align_opts* opts);

@@ -145,9 +145,13 @@ struct wca_engine {
 
   // ---- run-time sized buffers
   GrowBuf cap, wws, colnorm, scores, sel, selsc, matrix, trace, path, pathlen, jump, tmp0, tmp1;
-  int* res_host = nullptr;  // pinned results staging
-  size_t res_host_ints = 0;
-  int last_topk = 0, last_ntok_max = 0, last_batch = 0;
+  // results ring: up to 2 wca_align_batch_enqueue calls may be in flight before their _fetch
+  int* res_host[2] = {nullptr, nullptr};  // pinned results staging
+  size_t res_host_ints[2] = {0, 0};
+  hipEvent_t res_ev[2] = {};
+  int res_topk[2] = {0, 0}, res_ntok[2] = {0, 0}, res_batch[2] = {0, 0};
+  unsigned long enq_count = 0, fetch_count = 0;
+  int last_batch = 0;
 
   hipEvent_t ev[9] = {};
   hipEvent_t kev[64] = {};   // start/stop pairs around the encoder MLP fc1 GEMM of each layer (dominant kernel)
@@ -652,13 +656,13 @@ int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH,
   return WCA_OK;
 }
 
-int ensure_res_host(wca_engine* e, size_t ints) {
-  if (ints <= e->res_host_ints) return WCA_OK;
-  if (e->res_host) (void)hipHostFree(e->res_host);
-  e->res_host = nullptr;
-  e->res_host_ints = 0;
-  HIPCHK(hipHostMalloc((void**)&e->res_host, ints * sizeof(int), hipHostMallocDefault));
-  e->res_host_ints = ints;
+int ensure_res_host(wca_engine* e, int slot, size_t ints) {
+  if (ints <= e->res_host_ints[slot]) return WCA_OK;
+  if (e->res_host[slot]) (void)hipHostFree(e->res_host[slot]);
+  e->res_host[slot] = nullptr;
+  e->res_host_ints[slot] = 0;
+  HIPCHK(hipHostMalloc((void**)&e->res_host[slot], ints * sizeof(int), hipHostMallocDefault));
+  e->res_host_ints[slot] = ints;
   return WCA_OK;
 }
 
@@ -701,6 +705,7 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   HIPCHK(hipHostMalloc((void**)&e->meta_host, sizeof(int) * META_SLOTS * 4 * max_batch, hipHostMallocDefault));
   for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
   for (auto& ev : e->kev) HIPCHK(hipEventCreate(&ev));
+  for (auto& ev : e->res_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   e->ev_valid = true;
   // constant tables of the STFT
   {
@@ -728,7 +733,10 @@ void wca_engine_destroy(wca_engine* e) {
   if (e->wslab) (void)hipFree(e->wslab);
   if (e->aslab) (void)hipFree(e->aslab);
   if (e->meta_host) (void)hipHostFree(e->meta_host);
-  if (e->res_host) (void)hipHostFree(e->res_host);
+  for (int i = 0; i < 2; ++i) {
+    if (e->res_host[i]) (void)hipHostFree(e->res_host[i]);
+    if (e->res_ev[i]) (void)hipEventDestroy(e->res_ev[i]);
+  }
   if (e->ev_valid)
   {
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
@@ -1180,6 +1188,7 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int rc = check_ready(e);
   if (rc) return rc;
   if (!pcm_dev || !n_samples_host || !tokens_dev || !n_tok_host || !max_frames_host || !o) return fail(WCA_ERR_INVALID, "null argument");
+  if (e->enq_count - e->fetch_count >= 2) return fail(WCA_ERR_STATE, "two batches already in flight: call wca_align_batch_fetch first");
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
   if (o->aggregation == WCA_AGGR_TOPK && o->topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0 (timing.py:92)");
@@ -1243,31 +1252,37 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   rc = run_select_aggregate_dtw(e, (const float*)e->wws.p, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer);
   if (rc) return rc;
   record(e, 7);
-  // results -> pinned staging
+  // results -> pinned staging (ring of 2 so the host can post-process batch i while batch i+1 runs)
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
-  rc = ensure_res_host(e, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1));
+  const int rs = (int)(e->enq_count & 1);
+  rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1));
   if (rc) return rc;
   if (n_tok_max - o->sot_len - 1 >= 1)
-    HIPCHK(hipMemcpyAsync(e->res_host, e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->res_host[rs], e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, e->stream));
   if (k > 0)
-    HIPCHK(hipMemcpyAsync(e->res_host + (size_t)batch * n_tok_max, e->sel.p, sizeof(int) * (size_t)batch * k, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max, e->sel.p, sizeof(int) * (size_t)batch * k, hipMemcpyDeviceToHost, e->stream));
   record(e, 8);
+  HIPCHK(hipEventRecord(e->res_ev[rs], e->stream));
+  e->res_batch[rs] = batch;
+  e->res_ntok[rs] = n_tok_max;
+  e->res_topk[rs] = k;
   e->last_batch = batch;
-  e->last_ntok_max = n_tok_max;
-  e->last_topk = k;
+  e->enq_count++;
   return WCA_OK;
 }
 
 int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int32_t* jump_frame_host, int32_t* sel_idx_host) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   HIPCHK(hipSetDevice(e->device));
-  if (batch != e->last_batch || n_tok_max != e->last_ntok_max) return fail(WCA_ERR_STATE, "fetch does not match the last enqueue");
-  HIPCHK(hipStreamSynchronize(e->stream));
-  if (jump_frame_host) memcpy(jump_frame_host, e->res_host, sizeof(int) * (size_t)batch * n_tok_max);
-  if (sel_idx_host && e->last_topk > 0) {
-    if (topk != e->last_topk) return fail(WCA_ERR_STATE, "topk does not match the last enqueue");
-    memcpy(sel_idx_host, e->res_host + (size_t)batch * n_tok_max, sizeof(int) * (size_t)batch * topk);
-  }
+  if (e->fetch_count >= e->enq_count) return fail(WCA_ERR_STATE, "nothing to fetch");
+  const int rs = (int)(e->fetch_count & 1);  // oldest un-fetched batch
+  if (batch != e->res_batch[rs] || n_tok_max != e->res_ntok[rs]) return fail(WCA_ERR_STATE, "fetch does not match the oldest pending enqueue");
+  if (sel_idx_host && e->res_topk[rs] > 0 && topk != e->res_topk[rs]) return fail(WCA_ERR_STATE, "topk does not match the pending enqueue");
+  HIPCHK(hipEventSynchronize(e->res_ev[rs]));
+  if (jump_frame_host) memcpy(jump_frame_host, e->res_host[rs], sizeof(int) * (size_t)batch * n_tok_max);
+  if (sel_idx_host && e->res_topk[rs] > 0)
+    memcpy(sel_idx_host, e->res_host[rs] + (size_t)batch * n_tok_max, sizeof(int) * (size_t)batch * topk);
+  e->fetch_count++;
   return WCA_OK;
 }
 
