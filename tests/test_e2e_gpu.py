@@ -157,3 +157,47 @@ def test_north_star_config_parity_medium_dims(wca):
     assert np.all(np.abs(st - rst) <= 0.0201) and np.all(np.abs(en - ren) <= 0.0201)
     assert len(set(lh for _, lh, _ in scores) & set(lh for _, lh, _ in rscores)) >= 9
     del model
+
+
+def test_large_v3_shape_family(wca):
+    """n_mels=128, d=1280, 20 heads, vocab 51866 (large-v3 shapes, 1 layer each to keep the oracle fast)."""
+    from oracle import timing_ref, whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1)
+    sd = syn.random_state_dict(dims, seed=2, cross_qk_std=0.06)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2).load_state_dict(sd)
+    tok = tk.get_tokenizer(True, language="English")
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 3, 48000, 24)
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 128, model=model)
+    ref_mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), audio.mel_filters(128))
+    assert (mel.cpu() - ref_mel).abs().max().item() < 2e-4
+    w, logits = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, 150, medfilt_width=7)
+    rw, rlogits = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), whisper_ref.WhisperRef(sd, dims), 150, 7, 1.0)
+    assert tuple(w.shape) == (1, 20, len(tokens), 150)
+    assert (w.cpu() - rw).abs().max().item() < 5e-3
+    assert ((logits.cpu() - rlogits).abs().max() / rlogits.abs().max()).item() < 5e-3
+    del model
+
+
+def test_edge_cases_short_text_and_single_word(wca, setup):
+    """T = 1 (one character): one word + eot -> one (start, end); T = 0 -> the degenerate empty return."""
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pcm = syn.synth_audio(5, 16000)
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    for text in ["a", "ab cd"]:
+        tt = rt.encode(text, tok, "char")
+        tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]).cuda()
+        w, _ = tm.get_attentions(mel, tokens, model, tok, 50, medfilt_width=3)
+        words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "mean")
+        assert words[-1] == "<|endoftext|>" and len(st) == len(words) - 1 == len(text.split())
+        assert tuple(matrix.shape) == (len(tt) + 1, 50) and st[0] == 0.0 and np.all(en >= st)
+    # empty text: 5 framing tokens only -> N = 1 DTW row, and force_align returns the degenerate value
+    tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, tok.eot]).cuda()
+    w, _ = tm.get_attentions(mel, tokens, model, tok, 50, medfilt_width=3)
+    assert tm.force_align(w, [], tok, "char", "topk", topk=2) == [[], [], [], [], None]
+    # max_frames = 1 and medfilt wider than the row (returned unfiltered, like whisper.timing.median_filter)
+    tt = rt.encode("hi", tok, "char")
+    tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]).cuda()
+    w, _ = tm.get_attentions(mel, tokens, model, tok, 2, medfilt_width=7)
+    assert tuple(w.shape)[-1] == 2 and torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-5)

@@ -595,8 +595,16 @@ int validate_lengths(int B, int n_tok_max, const int32_t* n_tok, const int32_t* 
 
 // scores/top-k/aggregate/DTW on a dense weights tensor [B][LH][n_max][Fmax] whose column norms and
 // scores are already in e->colnorm / e->scores.
+struct Remat {
+  const float* qk = nullptr;
+  long qk_bs = 0, qk_hs = 0;
+  int qk_ld = 0;
+  const float* rowstats = nullptr;
+};
+
 int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH, int n_max, int Fmax, const int* n_tok_dev,
-                             const int* n_frames_dev, const int* dtwN_dev, const wca_align_opts* o, int L_layers) {
+                             const int* n_frames_dev, const int* dtwN_dev, const wca_align_opts* o, int L_layers,
+                             const Remat* rm = nullptr) {
   hipStream_t s = e->stream;
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
   if (o->aggregation == WCA_AGGR_TOPK) {
@@ -618,6 +626,15 @@ int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH,
   g.row_lo = o->sot_len;
   g.row_hi_trim = 1;
   g.matrix = (float*)e->matrix.p;
+  if (rm) {
+    g.qk = rm->qk;
+    g.qk_bs = rm->qk_bs;
+    g.qk_hs = rm->qk_hs;
+    g.qk_ld = rm->qk_ld;
+    g.rowstats = rm->rowstats;
+    g.medfilt_width = o->medfilt_width;
+    g.qk_scale = o->qk_scale;
+  }
   if (o->aggregation == WCA_AGGR_TOPK) {
     g.sel_idx = (const int*)e->sel.p;
     g.n_sel = k;
@@ -1224,7 +1241,9 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   rc = run_decoder(e, tokens_dev, batch, n_tok_max, (float*)e->cap.p, Fpad, Fmax, nullptr);
   if (rc) return rc;
   record(e, 4);
-  HIPCHK(e->wws.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * Fmax));
+  // the softmaxed maps are NOT materialised on this path (53 MB per utterance): head_stats keeps per-row
+  // (max, sum) and the aggregation re-derives the values of the few selected heads from the captured logits
+  HIPCHK(e->wws.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * 2));
   HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)batch * LH * Fmax));
   HIPCHK(e->scores.ensure(sizeof(float) * (size_t)batch * LH));
   HeadStatsArgs h{};
@@ -1232,8 +1251,8 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   h.qk_bs = (long)LH * n_tok_max * Fpad;
   h.qk_hs = (long)n_tok_max * Fpad;
   h.qk_ld = Fpad;
-  h.weights = (float*)e->wws.p;
-  h.w_bs = (long)LH * n_tok_max * Fmax;
+  h.weights = nullptr;
+  h.rowstats = (float*)e->wws.p;
   h.n_tok = rows[1];
   h.n_frames = rows[2];
   h.n_tok_max = n_tok_max;
@@ -1249,7 +1268,13 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   h.w_cov = o->w_coverage;
   HIPCHK(launch_head_stats(h, e->stream));
   record(e, 5);
-  rc = run_select_aggregate_dtw(e, (const float*)e->wws.p, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer);
+  Remat rm;
+  rm.qk = h.qk;
+  rm.qk_bs = h.qk_bs;
+  rm.qk_hs = h.qk_hs;
+  rm.qk_ld = h.qk_ld;
+  rm.rowstats = h.rowstats;
+  rc = run_select_aggregate_dtw(e, nullptr, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer, &rm);
   if (rc) return rc;
   record(e, 7);
   // results -> pinned staging (ring of 2 so the host can post-process batch i while batch i+1 runs)

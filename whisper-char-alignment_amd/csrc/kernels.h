@@ -93,6 +93,8 @@ struct HeadStatsArgs {
   int n_tok_max, n_frames_max;  // strides of the dense `weights` layout: [head][n_tok_max][n_frames_max]
   float* colnorm;          // [B][LH][n_frames_max] per-head column L2 norms
   float* scores;           // [B][LH]
+  float* rowstats;         // optional [B][LH][n_tok_max][2] = (row max of med*scale, sum of exp) so that selected
+                           // heads can be re-materialised later without storing `weights`
   int LH, B, medfilt_width;
   float qk_scale, w_col, w_row, w_cov;
   int input_is_weights;    // 1: `qk` already holds softmaxed weights (filter_attention on a given tensor): no median/softmax
@@ -111,6 +113,10 @@ struct AggregateArgs {
   const int* n_tok; const int* n_frames;
   int row_lo, row_hi_trim; // output rows [row_lo, n_tok - row_hi_trim)
   float* matrix;           // [B][n_tok_max][n_frames_max]
+  // recompute mode (weights == nullptr): re-derive the softmaxed value from the captured logits + rowstats
+  const float* qk; long qk_bs; long qk_hs; int qk_ld;
+  const float* rowstats;   // [B][LH][n_tok_max][2]
+  int medfilt_width; float qk_scale;
 };
 hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s);
 

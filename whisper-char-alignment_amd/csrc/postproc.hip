@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
         sum += v[i];
       }
       sum = wave_sum(sum);
+      if (a.rowstats && lane == 0) {
+        float* rsp = a.rowstats + (((long)b * a.LH + head) * a.n_tok_max + t) * 2;
+        rsp[0] = mx;
+        rsp[1] = sum;
+      }
     }
     float rsq = 0.f;
 #pragma unroll
@@ -224,6 +229,28 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ sco
   }
 }
 
+// value of the filtered + softmaxed map of head `hd` at (t, f), recomputed from the captured logits exactly as
+// head_stats_kernel computed it (same median, same expf(v - max) / sum), so both paths give identical bits
+__device__ __forceinline__ float remat_weight(const AggregateArgs& a, int b, int hd, int t, int f, int F) {
+  const float* row = a.qk + (long)b * a.qk_bs + (long)hd * a.qk_hs + (long)t * a.qk_ld;
+  const float* rs = a.rowstats + (((long)b * a.LH + hd) * a.n_tok_max + t) * 2;
+  const int w = a.medfilt_width, pad = w >> 1;
+  float med;
+  if (w <= 1 || F <= pad) {
+    med = row[f];
+  } else {
+    float win[33];
+    for (int k = 0; k < w; ++k) {
+      int idx = f - pad + k;
+      idx = idx < 0 ? -idx : idx;
+      idx = idx >= F ? 2 * (F - 1) - idx : idx;
+      win[k] = row[idx];
+    }
+    med = (w == 3) ? median_w<3>(win) : (w == 5) ? median_w<5>(win) : (w == 7) ? median_w<7>(win) : median_generic(win, w);
+  }
+  return expf(med * a.qk_scale - rs[0]) / rs[1];
+}
+
 __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
   const int b = blockIdx.z;
   const int n = a.n_tok[b], F = a.n_frames[b];
@@ -231,7 +258,7 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
   const int f = blockIdx.x * 256 + threadIdx.x;
   if (t >= n - a.row_hi_trim || f >= F) return;
   const int Fmax = a.n_frames_max;
-  const float* W = a.weights + (long)b * a.w_bs;
+  const float* W = a.weights ? a.weights + (long)b * a.w_bs : nullptr;
   const float* CN = a.colnorm + (long)b * a.LH * Fmax;
   float acc = 0.f;
   int cnt;
@@ -240,13 +267,16 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
     for (int s = 0; s < a.n_sel; ++s) {
       const int hd = a.sel_idx[(long)b * a.n_sel + s];
       if (hd < 0) continue;
-      acc += W[((long)hd * a.n_tok_max + t) * Fmax + f] / CN[(long)hd * Fmax + f];
+      const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
+      acc += wv / CN[(long)hd * Fmax + f];
       ++cnt;
     }
   } else {
     cnt = a.LH - a.head_lo;
-    for (int hd = a.head_lo; hd < a.LH; ++hd)
-      acc += W[((long)hd * a.n_tok_max + t) * Fmax + f] / CN[(long)hd * Fmax + f];
+    for (int hd = a.head_lo; hd < a.LH; ++hd) {
+      const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
+      acc += wv / CN[(long)hd * Fmax + f];
+    }
   }
   a.matrix[((long)b * a.n_tok_max + (t - a.row_lo)) * Fmax + f] = acc / (float)cnt;
 }
