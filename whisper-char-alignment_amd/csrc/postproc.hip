@@ -104,23 +104,44 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
   }
   float rown_acc = 0.f;
 
+  // the next row of this wave is fetched into registers while the current one is processed
+  float nxt[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = lane + 64 * i;
+    nxt[i] = (wave < n && f < F) ? qk[(long)wave * a.qk_ld + f] : -INFINITY;
+  }
   for (int t = wave; t < n; t += 4) {
-    const float* src = qk + (long)t * a.qk_ld;
     float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = nxt[i];
+    if (t + 4 < n) {
+      const float* srcn = qk + (long)(t + 4) * a.qk_ld;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        nxt[i] = (f < F) ? srcn[f] : -INFINITY;
+      }
+    }
     if (do_med) {
-      load_row_reflect(src, rowbuf, F, pad, lane);
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) {
+        const int f = lane + 64 * i;
+        if (f < F) rowbuf[HALO + f] = v[i];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane < pad) {
+        const int k = lane + 1;
+        rowbuf[HALO - k] = rowbuf[HALO + k];
+        rowbuf[HALO + F - 1 + k] = rowbuf[HALO + F - 1 - k];
+      }
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int i = 0; i < NPL; ++i) {
         const int f = lane + 64 * i;
         v[i] = (f < F) ? median_any(rowbuf + HALO + f - pad, w) : -INFINITY;
       }
       __builtin_amdgcn_wave_barrier();
-    } else {
-#pragma unroll
-      for (int i = 0; i < NPL; ++i) {
-        const int f = lane + 64 * i;
-        v[i] = (f < F) ? src[f] : -INFINITY;
-      }
     }
     float sum = 1.0f;
     if (!a.input_is_weights) {
