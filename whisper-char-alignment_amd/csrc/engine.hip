@@ -99,8 +99,10 @@ struct wca_engine {
   wca_model_dims dims;
   int device = 0;
   int max_batch = 1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // phase 1 (log-mel, encoder, cross-K/V) and every non-batched entry point
   hipStream_t own_stream = nullptr;
+  hipStream_t stream2 = nullptr;     // phase 2 of wca_align_batch (decoder, post-processing, DTW, D2H): overlaps the next batch's phase 1
+  hipEvent_t ev_kv[2] = {};          // cross-K/V of batch slot ready (recorded on `stream`)
   bool finalized = false;
   bool have_filters = false;
   bool profiling = false;
@@ -133,6 +135,7 @@ struct wca_engine {
   half_t* att = nullptr;   // [B*1500][d]
   half_t* hid = nullptr;   // [B*1500][4d]
   half_t* kv = nullptr;    // [B*1500][L*2*d]
+  half_t* kv_alt = nullptr; // second cross-K/V buffer (batches alternate, see wca_align_batch_enqueue)
   float* xd = nullptr;     // [B*448][d]
   half_t* xdn = nullptr;
   half_t* qkv_d = nullptr;
@@ -251,6 +254,7 @@ size_t layout_arena(wca_engine* e, char* base) {
   e->att = carve<half_t>(cur, B * N_CTX * d);
   e->hid = carve<half_t>(cur, B * N_CTX * 4 * d);
   e->kv = carve<half_t>(cur, B * N_CTX * L * 2 * dt);
+  e->kv_alt = carve<half_t>(cur, B * N_CTX * L * 2 * dt);
   e->xd = carve<float>(cur, B * MAX_TOK * dt);
   e->xdn = carve<half_t>(cur, B * MAX_TOK * dt);
   e->qkv_d = carve<half_t>(cur, B * MAX_TOK * 3 * dt);
@@ -359,8 +363,15 @@ int load_block_tensor(wca_engine* e, LayerW& l, bool is_dec, int li, const std::
   return 1;  // unknown (ignored)
 }
 
-void record(wca_engine* e, int i) {
-  if (e->profiling && e->ev_valid) (void)hipEventRecord(e->ev[i], e->stream);
+void record(wca_engine* e, int i, hipStream_t s = nullptr) {
+  if (e->profiling && e->ev_valid) (void)hipEventRecord(e->ev[i], s ? s : e->stream);
+}
+
+// Entry points other than wca_align_batch* share the phase-2 scratch (capture, norms, DTW buffers) with a batch
+// that may still be running on stream2: order them behind it.
+int join_phase2(wca_engine* e) {
+  if (e->enq_count > e->fetch_count) HIPCHK(hipStreamWaitEvent(e->stream, e->res_ev[(e->enq_count - 1) & 1], 0));
+  return WCA_OK;
 }
 
 // ---- encoder: mel_tm (f16 time-major) -> xn = ln_post(x) (f16) and optionally x (f32)
@@ -444,18 +455,21 @@ int run_encoder(wca_engine* e, int B) {
 }
 
 // cross-attention K/V of every decoder layer in one GEMM: kv[b*1500 + t][(2l + {0,1})*dt + c]
-int run_cross_kv(wca_engine* e, int B) {
+int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr) {
+  if (!kvbuf) kvbuf = e->kv;
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
-  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, e->kv, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0, 3));
+  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, kvbuf, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0, 3));
   return WCA_OK;
 }
 
 // decoder with capture. tokens_dev [B][n]; capture -> cap [B][L*H][n][Fpad] (first Fcap keys)
-int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out) {
+int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out,
+                hipStream_t s = nullptr, const half_t* kvbuf = nullptr) {
   const wca_model_dims& D = e->dims;
   const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
-  hipStream_t s = e->stream;
+  if (!s) s = e->stream;
+  if (!kvbuf) kvbuf = e->kv;
   const int M = B * n;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
   HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, s));
@@ -489,8 +503,8 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
       a.Q = e->q_d;
       a.q_bs = (long)n * dt;
       a.q_rs = dt;
-      a.K = e->kv + (size_t)(2 * li) * dt;
-      a.V = e->kv + (size_t)(2 * li + 1) * dt;
+      a.K = kvbuf + (size_t)(2 * li) * dt;
+      a.V = kvbuf + (size_t)(2 * li + 1) * dt;
       a.k_bs = a.v_bs = (long)N_CTX * L * 2 * dt;
       a.k_rs = a.v_rs = L * 2 * dt;
       a.O = e->att_d;
@@ -604,8 +618,8 @@ struct Remat {
 
 int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH, int n_max, int Fmax, const int* n_tok_dev,
                              const int* n_frames_dev, const int* dtwN_dev, const wca_align_opts* o, int L_layers,
-                             const Remat* rm = nullptr) {
-  hipStream_t s = e->stream;
+                             const Remat* rm = nullptr, hipStream_t s_in = nullptr) {
+  hipStream_t s = s_in ? s_in : e->stream;
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
   if (o->aggregation == WCA_AGGR_TOPK) {
     HIPCHK(e->sel.ensure(sizeof(int) * (size_t)B * k));
@@ -644,7 +658,7 @@ int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH,
     g.head_lo = (L_layers / 2) * H;  // ws[n_layers//2:]  (timing.py:88)
   }
   HIPCHK(launch_aggregate(g, s));
-  record(e, 6);
+  record(e, 6, s);
 
   const int Nmax = n_max - o->sot_len - 1;
   if (Nmax >= 1) {
@@ -710,7 +724,9 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   e->device = device_ordinal;
   e->max_batch = max_batch;
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
   e->stream = e->own_stream;
+  for (auto& ev : e->ev_kv) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   e->wslab_bytes = layout_weights(e, nullptr);
   HIPCHK(hipMalloc((void**)&e->wslab, e->wslab_bytes));
   HIPCHK(hipMemset(e->wslab, 0, e->wslab_bytes));
@@ -759,6 +775,9 @@ void wca_engine_destroy(wca_engine* e) {
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->kev) (void)hipEventDestroy(ev);
   }
+  for (auto& ev : e->ev_kv)
+    if (ev) (void)hipEventDestroy(ev);
+  if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
@@ -773,6 +792,7 @@ int wca_engine_synchronize(wca_engine* e) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream2));
   return WCA_OK;
 }
 
@@ -917,6 +937,7 @@ int wca_finalize_weights(wca_engine* e) {
 int wca_log_mel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host, int batch, float* mel_out_dev) {
   if (!e || !pcm_dev || !n_samples_host || !mel_out_dev) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   for (int b = 0; b < batch; ++b)
     if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
@@ -932,6 +953,7 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
                        float* logits_out_dev) {
   int rc = check_ready(e);
   if (rc) return rc;
+  if ((rc = join_phase2(e))) return rc;
   if (!mel_dev || !tokens_dev || !max_frames_host || !weights_out_dev) return fail(WCA_ERR_INVALID, "null argument");
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   if (medfilt_width < 1 || !(medfilt_width & 1) || medfilt_width > 33) return fail(WCA_ERR_INVALID, "medfilt_width must be odd and <= 33");
@@ -986,6 +1008,7 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
 int wca_median_filter(wca_engine* e, const float* in_dev, float* out_dev, int64_t rows, int F, int width) {
   if (!e || !in_dev || !out_dev) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (width < 1 || !(width & 1) || width > 33) return fail(WCA_ERR_INVALID, "filter width must be odd and <= 33");
   HIPCHK(launch_median_filter(in_dev, out_dev, rows, F, width, e->stream));
   return WCA_OK;
@@ -1029,6 +1052,7 @@ int wca_filter_attention(wca_engine* e, const float* attns_dev, int L, int H, in
                          float w_coverage, float* scores_host, int32_t* sel_idx_host, float* sel_score_host) {
   if (!e || !attns_dev) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0");
   int* rows[4];
   int rc = stats_on_weights(e, attns_dev, L, H, n, F, w_colnorm, w_rownorm, w_coverage, rows, 0);
@@ -1050,6 +1074,7 @@ int wca_force_align(wca_engine* e, const float* ws_dev, int L, int H, int n, int
                     float* sel_score_host) {
   if (!e || !ws_dev || !o || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
   if (o->aggregation == WCA_AGGR_TOPK && o->topk < 1) return fail(WCA_ERR_INVALID, "topk must be > 0 (timing.py:92)");
   const int N = n - o->sot_len - 1;
@@ -1108,6 +1133,7 @@ static int dtw_dev_common(wca_engine* e, const float* matrix_dev, int P, int N, 
 int wca_dtw(wca_engine* e, const float* matrix_host, int N, int M, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host) {
   if (!e || !matrix_host || !text_idx_host || !time_idx_host || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (N < 1 || M < 1) return fail(WCA_ERR_INVALID, "empty DTW matrix");
   HIPCHK(e->tmp0.ensure(sizeof(float) * (size_t)N * M));
   HIPCHK(hipMemcpyAsync(e->tmp0.p, matrix_host, sizeof(float) * (size_t)N * M, hipMemcpyHostToDevice, e->stream));
@@ -1130,6 +1156,7 @@ int wca_dtw(wca_engine* e, const float* matrix_host, int N, int M, int32_t* text
 int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int M, int32_t* jump_frame_host) {
   if (!e || !matrix_dev || !jump_frame_host) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   if (P < 1) return fail(WCA_ERR_INVALID, "P < 1");
   int rc = dtw_dev_common(e, matrix_dev, P, N, M, true);
   if (rc) return rc;
@@ -1142,6 +1169,7 @@ int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int
                     int32_t* jump_frame_host) {
   if (!e || !ws_dev || !jump_frame_host) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
   const int LH = L * H, N = n - sot_len - 1;
   if (sot_len < 0 || N < 1) return fail(WCA_ERR_INVALID, "n=%d leaves no rows after the [sot_len:-1] slice", n);
   int* rows[4];
@@ -1227,6 +1255,11 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int* rows[4];
   rc = stage_meta(e, batch, n_samples_host, n_tok_host, max_frames_host, dn.data(), rows);
   if (rc) return rc;
+  // ---- phase 1 on `stream`: log-mel, encoder, cross-K/V of all decoder layers into this batch's K/V buffer.
+  // (The buffer was last read by the batch two enqueues ago, which has been fetched: at most 2 are in flight.)
+  const int bs = (int)(e->enq_count & 1);
+  half_t* kvbuf = bs ? e->kv_alt : e->kv;
+  hipStream_t s2 = e->stream2;
   record(e, 0);
   rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
   if (rc) return rc;
@@ -1234,13 +1267,17 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   rc = run_encoder(e, batch);
   if (rc) return rc;
   record(e, 2);
-  rc = run_cross_kv(e, batch);
+  rc = run_cross_kv(e, batch, kvbuf);
   if (rc) return rc;
   record(e, 3);
+  HIPCHK(hipEventRecord(e->ev_kv[bs], e->stream));
+  // ---- phase 2 on `stream2`: decoder with capture, head statistics, top-k, aggregation, DTW, D2H. These are
+  // latency-bound kernels with few workgroups; on their own stream they overlap the NEXT batch's phase 1.
+  HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
   HIPCHK(e->cap.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * Fpad));
-  rc = run_decoder(e, tokens_dev, batch, n_tok_max, (float*)e->cap.p, Fpad, Fmax, nullptr);
+  rc = run_decoder(e, tokens_dev, batch, n_tok_max, (float*)e->cap.p, Fpad, Fmax, nullptr, s2, kvbuf);
   if (rc) return rc;
-  record(e, 4);
+  record(e, 4, s2);
   // the softmaxed maps are NOT materialised on this path (53 MB per utterance): head_stats keeps per-row
   // (max, sum) and the aggregation re-derives the values of the few selected heads from the captured logits
   HIPCHK(e->wws.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * 2));
@@ -1266,28 +1303,28 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   h.w_col = o->w_colnorm;
   h.w_row = o->w_rownorm;
   h.w_cov = o->w_coverage;
-  HIPCHK(launch_head_stats(h, e->stream));
-  record(e, 5);
+  HIPCHK(launch_head_stats(h, s2));
+  record(e, 5, s2);
   Remat rm;
   rm.qk = h.qk;
   rm.qk_bs = h.qk_bs;
   rm.qk_hs = h.qk_hs;
   rm.qk_ld = h.qk_ld;
   rm.rowstats = h.rowstats;
-  rc = run_select_aggregate_dtw(e, nullptr, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer, &rm);
+  rc = run_select_aggregate_dtw(e, nullptr, batch, LH, n_tok_max, Fmax, rows[1], rows[2], rows[3], o, D.n_text_layer, &rm, s2);
   if (rc) return rc;
-  record(e, 7);
+  record(e, 7, s2);
   // results -> pinned staging (ring of 2 so the host can post-process batch i while batch i+1 runs)
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
   const int rs = (int)(e->enq_count & 1);
   rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1));
   if (rc) return rc;
   if (n_tok_max - o->sot_len - 1 >= 1)
-    HIPCHK(hipMemcpyAsync(e->res_host[rs], e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipMemcpyAsync(e->res_host[rs], e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, s2));
   if (k > 0)
-    HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max, e->sel.p, sizeof(int) * (size_t)batch * k, hipMemcpyDeviceToHost, e->stream));
-  record(e, 8);
-  HIPCHK(hipEventRecord(e->res_ev[rs], e->stream));
+    HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max, e->sel.p, sizeof(int) * (size_t)batch * k, hipMemcpyDeviceToHost, s2));
+  record(e, 8, s2);
+  HIPCHK(hipEventRecord(e->res_ev[rs], s2));
   e->res_batch[rs] = batch;
   e->res_ntok[rs] = n_tok_max;
   e->res_topk[rs] = k;
@@ -1419,6 +1456,7 @@ int wca_test_layernorm(wca_engine* e, const float* x, const float* g, const floa
 int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_out_dev) {
   int rc = check_ready(e);
   if (rc) return rc;
+  if ((rc = join_phase2(e))) return rc;
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   const wca_model_dims& D = e->dims;
   const size_t nel = (size_t)D.n_mels * N_FRAMES;
