@@ -17,6 +17,7 @@
  *   wca_force_align        timing.py:69-103  force_align() up to and including dtw(-matrix):
  *                          aggregation "mean" (timing.py:84-89) / "topk" (timing.py:91-97), the
  *                          [len(sot_sequence):-1] slice (timing.py:102), DTW + backtrace (timing.py:103)
+ *   wca_default_find_alignment  timing.py:116-186 default_find_alignment (std/mean normalised alignment heads)
  *   wca_dtw                timing.py:103     whisper.timing.dtw -> dtw_cpu + backtrace
  *   wca_probe_heads        probe_oracle.py:83-90  per-head force_align sweep (one DTW per head)
  *   wca_align_batch        infer_ali.py:93-101 + dataset.py:47-48: the whole per-utterance pipeline
@@ -130,6 +131,15 @@ int wca_filter_attention(wca_engine* e, const float* attns_dev, int L, int H, in
 int wca_force_align(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const wca_align_opts* opts,
                     float* matrix_host, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host,
                     int32_t* sel_idx_host, float* sel_score_host);
+
+/* timing.py:116-186 default_find_alignment (openai-whisper's own aligner, `--default_whisper_timing`), the part after
+ * median filter + softmax: weights of the given alignment heads (flat ids l*H + h) are normalised per head and frame
+ * over the token axis, (w - mean) / std with population std (timing.py:159-160), averaged over the heads (:162),
+ * sliced [sot_len:-1] (:163) and aligned with dtw(-matrix) (:165; the dtw_cpu tie rule is used).
+ * ws_dev [L][H][n][F] as returned by wca_get_attentions; outputs as in wca_force_align. */
+int wca_default_find_alignment(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const int32_t* heads_host,
+                                int n_heads, int sot_len, float* matrix_host, int32_t* text_idx_host,
+                                int32_t* time_idx_host, int32_t* path_len_host);
 
 /* DTW on the NEGATED matrix exactly like `dtw(-matrix)`; matrix_host [N][M] f32 row-major.
  * text_idx_host / time_idx_host capacity N + M. */

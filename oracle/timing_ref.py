@@ -194,3 +194,14 @@ def force_align(ws, tokens, tokenizer, aligned_unit_type="subword", aggregation=
         return [[], [], [], [], None]
     start_times, end_times = jumps_to_times(text_indices, time_indices, word_tokens)
     return words, start_times, end_times, matrix, scores
+
+
+# ------------------------------------------------------------------ timing.py:157-165 (default_find_alignment, arithmetic part)
+def default_alignment_matrix(weights, heads, sot_len):
+    """weights [L, H, n, F] already median filtered + softmaxed (timing.py:157-158); heads: list of (l, h).
+    std/mean normalisation over the token axis, mean over heads, [sot:-1] slice (timing.py:159-163)."""
+    w = torch.stack([weights[l][h] for l, h in heads])
+    std, mean = torch.std_mean(w, dim=-2, keepdim=True, unbiased=False)
+    w = (w - mean) / std
+    matrix = w.mean(axis=0)
+    return matrix[sot_len:-1]

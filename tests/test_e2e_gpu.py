@@ -201,3 +201,26 @@ def test_edge_cases_short_text_and_single_word(wca, setup):
     tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]).cuda()
     w, _ = tm.get_attentions(mel, tokens, model, tok, 2, medfilt_width=7)
     assert tuple(w.shape)[-1] == 2 and torch.allclose(w.sum(-1), torch.ones_like(w.sum(-1)), atol=1e-5)
+
+
+def test_default_find_alignment_vs_oracle(wca, setup):
+    """--default_whisper_timing path (timing.py:116-186): std/mean-normalised alignment heads + DTW."""
+    from oracle import timing_ref, whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 41, 64000, 28)
+    max_frames = len(pcm) // 320
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    model.set_alignment_heads([(1, 0), (2, 3), (2, 1)])
+    words, st, en, matrix, _ = tm.default_find_alignment(model, tok, tt, mel, max_frames, medfilt_width=7)
+    # oracle on the engine's own weights: isolates the normalisation + DTW from the forward's f16 noise
+    w, _ = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, max_frames, medfilt_width=7)
+    ref_m = timing_ref.default_alignment_matrix(w.cpu(), model.alignment_heads, 3)
+    np.testing.assert_allclose(matrix.numpy(), ref_m.numpy(), rtol=2e-4, atol=2e-4)
+    ti, tj = timing_ref.dtw(-matrix)
+    jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+    _, word_tokens = tok.split_to_word_tokens(tt + [tok.eot])
+    wb = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
+    assert np.array_equal(st, (tj[jumps] / 50)[wb[:-1]]) and np.array_equal(en, (tj[jumps] / 50)[wb[1:]])
+    assert [w_.strip() for w_ in words[:-1]] == text.split()
+    model.set_alignment_heads([(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)])

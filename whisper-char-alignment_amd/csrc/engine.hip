@@ -1227,6 +1227,83 @@ int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int
   return WCA_OK;
 }
 
+int wca_default_find_alignment(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const int32_t* heads_host, int n_heads,
+                                int sot_len, float* matrix_host, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host) {
+  if (!e || !ws_dev || !heads_host || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
+  const int LH = L * H, N = n - sot_len - 1;
+  if (n_heads < 1) return fail(WCA_ERR_INVALID, "empty alignment head list");
+  if (sot_len < 0 || N < 1) return fail(WCA_ERR_INVALID, "n=%d leaves no rows after the [sot_len:-1] slice", n);
+  for (int i = 0; i < n_heads; ++i)
+    if (heads_host[i] < 0 || heads_host[i] >= LH) return fail(WCA_ERR_INVALID, "alignment head %d out of range", heads_host[i]);
+  int* rows[4];
+  HIPCHK(e->tmp1.ensure(sizeof(float) * (size_t)LH * F + sizeof(int) * (size_t)n_heads));
+  // column sums are needed next to the column norms: run the statistics pass with the colsum output enabled
+  if (L < 1 || H < 1 || n < 1 || n > MAX_TOK) return fail(WCA_ERR_INVALID, "bad shape L=%d H=%d n=%d", L, H, n);
+  if (F < 1 || F > N_CTX) return fail(WCA_ERR_TOO_LONG, "F=%d outside [1,%d]", F, N_CTX);
+  int32_t nt = n, nf = F, dn = N;
+  int rc = stage_meta(e, 1, nullptr, &nt, &nf, &dn, rows);
+  if (rc) return rc;
+  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)LH * F));
+  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)LH));
+  HeadStatsArgs h{};
+  h.qk = ws_dev;
+  h.qk_hs = (long)n * F;
+  h.qk_ld = F;
+  h.n_tok = rows[1];
+  h.n_frames = rows[2];
+  h.n_tok_max = n;
+  h.n_frames_max = F;
+  h.colnorm = (float*)e->colnorm.p;
+  h.colsum = (float*)e->tmp1.p;
+  h.scores = (float*)e->scores.p;
+  h.LH = LH;
+  h.B = 1;
+  h.medfilt_width = 1;
+  h.qk_scale = 1.f;
+  h.w_col = 1.f;
+  h.w_row = 1.f;
+  h.input_is_weights = 1;
+  HIPCHK(launch_head_stats(h, e->stream));
+  int* sel_dev = reinterpret_cast<int*>(reinterpret_cast<float*>(e->tmp1.p) + (size_t)LH * F);
+  HIPCHK(hipMemcpyAsync(sel_dev, heads_host, sizeof(int) * n_heads, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e->matrix.ensure(sizeof(float) * (size_t)n * F));
+  AggregateArgs g{};
+  g.weights = ws_dev;
+  g.w_bs = 0;
+  g.n_tok_max = n;
+  g.n_frames_max = F;
+  g.colnorm = (const float*)e->colnorm.p;
+  g.colsum = (const float*)e->tmp1.p;
+  g.sel_idx = sel_dev;
+  g.n_sel = n_heads;
+  g.LH = LH;
+  g.B = 1;
+  g.n_tok = rows[1];
+  g.n_frames = rows[2];
+  g.row_lo = sot_len;
+  g.row_hi_trim = 1;
+  g.matrix = (float*)e->matrix.p;
+  HIPCHK(launch_aggregate(g, e->stream));
+  rc = dtw_dev_common(e, (const float*)e->matrix.p, 1, N, F, false);
+  if (rc) return rc;
+  const int cap = N + F + 2;
+  std::vector<int> path(2 * (size_t)cap);
+  int plen = 0;
+  HIPCHK(hipMemcpyAsync(&plen, e->pathlen.p, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipMemcpyAsync(path.data(), e->path.p, sizeof(int) * 2 * cap, hipMemcpyDeviceToHost, e->stream));
+  if (matrix_host) HIPCHK(hipMemcpyAsync(matrix_host, e->matrix.p, sizeof(float) * (size_t)N * F, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  *path_len_host = plen;
+  if (text_idx_host && time_idx_host)
+    for (int i = 0; i < plen; ++i) {
+      text_idx_host[i] = path[cap - plen + i];
+      time_idx_host[i] = path[cap + cap - plen + i];
+    }
+  return WCA_OK;
+}
+
 int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
                             const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host, const int32_t* max_frames_host,
                             int batch, const wca_align_opts* o) {

@@ -92,6 +92,7 @@ struct HeadStatsArgs {
   const int* n_frames;     // [B] F per utterance (device)
   int n_tok_max, n_frames_max;  // strides of the dense `weights` layout: [head][n_tok_max][n_frames_max]
   float* colnorm;          // [B][LH][n_frames_max] per-head column L2 norms
+  float* colsum;           // optional [B][LH][n_frames_max] per-head column sums (default_find_alignment's std/mean)
   float* scores;           // [B][LH]
   float* rowstats;         // optional [B][LH][n_tok_max][2] = (row max of med*scale, sum of exp) so that selected
                            // heads can be re-materialised later without storing `weights`
@@ -117,6 +118,9 @@ struct AggregateArgs {
   const float* qk; long qk_bs; long qk_hs; int qk_ld;
   const float* rowstats;   // [B][LH][n_tok_max][2]
   int medfilt_width; float qk_scale;
+  // std_mean mode (timing.py:159-160, default_find_alignment): value = (w - mean_t) / std_t per head and frame,
+  // mean/std over the token axis (population std) from colsum / colnorm; colsum == nullptr => L2-norm mode
+  const float* colsum;
 };
 hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s);
 

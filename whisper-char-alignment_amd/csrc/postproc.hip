@@ -200,6 +200,7 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
     const float sm_ = ((red_sum[f] + red_sum[Fmax + f]) + red_sum[2 * Fmax + f]) + red_sum[3 * Fmax + f];
     const float cn = sqrtf(sq);
     cn_out[f] = cn;
+    if (a.colsum) a.colsum[((long)b * a.LH + head) * Fmax + f] = sm_;
     cn_part += cn;
     cov_part += fmaxf(sm_, 0.5f);
   }
@@ -281,23 +282,30 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
   const int Fmax = a.n_frames_max;
   const float* W = a.weights ? a.weights + (long)b * a.w_bs : nullptr;
   const float* CN = a.colnorm + (long)b * a.LH * Fmax;
+  const float* CS = a.colsum ? a.colsum + (long)b * a.LH * Fmax : nullptr;
   float acc = 0.f;
   int cnt;
+  auto contrib = [&](int hd) -> float {
+    const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
+    const float cn = CN[(long)hd * Fmax + f];
+    if (CS) {  // (w - mean) / std with population statistics over all n token rows
+      const float mean = CS[(long)hd * Fmax + f] / (float)n;
+      const float var = cn * cn / (float)n - mean * mean;
+      return (wv - mean) / sqrtf(fmaxf(var, 0.f));
+    }
+    return wv / cn;
+  };
   if (a.sel_idx) {
     cnt = 0;
     for (int s = 0; s < a.n_sel; ++s) {
       const int hd = a.sel_idx[(long)b * a.n_sel + s];
       if (hd < 0) continue;
-      const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
-      acc += wv / CN[(long)hd * Fmax + f];
+      acc += contrib(hd);
       ++cnt;
     }
   } else {
     cnt = a.LH - a.head_lo;
-    for (int hd = a.head_lo; hd < a.LH; ++hd) {
-      const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
-      acc += wv / CN[(long)hd * Fmax + f];
-    }
+    for (int hd = a.head_lo; hd < a.LH; ++hd) acc += contrib(hd);
   }
   a.matrix[((long)b * a.n_tok_max + (t - a.row_lo)) * Fmax + f] = acc / (float)cnt;
 }

@@ -92,6 +92,8 @@ class WhisperAMD:
         _lib.check(self._lib.wca_engine_create(C.byref(cd), index, self.max_batch, C.byref(self._h)))
         self._stream_bound = None
         self._finalized = False
+        # whisper.model.Whisper default: every head of the upper half of the decoder layers (set_alignment_heads overrides)
+        self.alignment_heads = [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
         filt = np.ascontiguousarray(mel_filters(dims.n_mels), dtype=np.float32)
         self._load_one("mel_filters", filt)
         if _register:
@@ -106,6 +108,14 @@ class WhisperAMD:
     @property
     def num_languages(self):
         return self.dims.n_vocab - 51765 - int(self.is_multilingual)
+
+    def set_alignment_heads(self, heads):
+        """heads: iterable of (layer, head) pairs used by timing.default_find_alignment."""
+        heads = [(int(l), int(h)) for l, h in heads]
+        for l, h in heads:
+            if not (0 <= l < self.dims.n_text_layer and 0 <= h < self.dims.n_text_head):
+                raise ValueError("alignment head (%d, %d) out of range" % (l, h))
+        self.alignment_heads = heads
 
     def to(self, device):
         if torch.device(device) != self.device:

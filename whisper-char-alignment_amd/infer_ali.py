@@ -37,7 +37,8 @@ from .dataset import TIMIT, LibriSpeech  # noqa: E402
 from .engine import WhisperAMD, dims_for, MAX_FRAMES, MAX_LENGTH  # noqa: E402
 from .metrics import eval_n1, eval_n1_strict, get_seg_metrics  # noqa: E402
 from .retokenize import encode, remove_punctuation  # noqa: E402
-from .timing import words_from_jump_frames  # noqa: E402
+from .timing import words_from_jump_frames, default_find_alignment  # noqa: E402
+from .audio import log_mel_spectrogram, pad_or_trim  # noqa: E402
 from .tokenizer import get_tokenizer  # noqa: E402
 
 DATASET = {"TIMIT": TIMIT, "LibriSpeech": LibriSpeech}
@@ -70,8 +71,6 @@ def infer_dataset(args):
     if args.n_mels != model.dims.n_mels:
         raise SystemExit("--n_mels %d does not match the checkpoint (%d); large-v3 needs --n_mels 128" % (args.n_mels, model.dims.n_mels))
     tokenizer = get_tokenizer(model.is_multilingual, language="English", vocab_path=args.vocab)
-    if args.default_whisper_timing:
-        raise SystemExit("--default_whisper_timing (upstream alignment-heads baseline) is not implemented in this engine yet")
     if args.teacher != "text":
         raise SystemExit("--teacher asr needs the greedy decode pre-pass, which is not implemented in this engine yet")
     dataset = DATASET[args.dataset](args.scp, n_mels=args.n_mels, device=device, model=model, compute_mel=False)
@@ -126,6 +125,16 @@ def infer_dataset(args):
         max_frames = duration // AUDIO_SAMPLES_PER_TOKEN
         if max_frames > MAX_FRAMES or len(tokens) > MAX_LENGTH or max_frames < 1:
             print(fid)
+            continue
+        if args.default_whisper_timing:  # per-utterance path (timing.py:116-186), not the fused batch path
+            mel = log_mel_spectrogram(pad_or_trim(audio), args.n_mels, model=model)
+            words, start_times, end_times, _ws, _ = default_find_alignment(model, tokenizer, text_tokens, mel, int(max_frames),
+                                                                         medfilt_width=args.medfilt_width)
+            local_times[n] = (np.asarray(start_times, dtype=np.float64), np.asarray(end_times, dtype=np.float64))
+            c, _ = eval_n1(ends, end_times, args.tolerance)
+            total_gts += len(ends)
+            total_preds += len(end_times)
+            corrects += c
             continue
         pcm = audio.numpy()[:min(duration, len(audio))]
         pending.append(dict(index=n, pcm=pcm, tokens=tokens, text_tokens=text_tokens, max_frames=int(max_frames), texts=texts,

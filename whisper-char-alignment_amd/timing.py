@@ -160,6 +160,36 @@ def force_align(ws, tokens, tokenizer, aligned_unit_type="subword", aggregation=
     return words, start_times, end_times, matrix, scores
 
 
+def default_find_alignment(model, tokenizer, text_tokens, mel, max_frames, *, medfilt_width=7, qk_scale=1.0):
+    """openai-whisper's own aligner as restated by the reference (timing.py:116-186, `--default_whisper_timing`):
+    the cross-attention maps of `model.alignment_heads` are median filtered, softmaxed, normalised per head and
+    frame over the token axis ((w - mean) / std, population std), averaged, sliced [sot:-1] and aligned with DTW;
+    words come from tokenizer.split_to_word_tokens. Returns (words, start_times, end_times, matrix, None)."""
+    sot_len = len(tokenizer.sot_sequence)
+    tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]).to(model.device)
+    weights, _logits = get_attentions(mel, tokens, model, tokenizer, max_frames, medfilt_width, qk_scale)
+    L, H, n, F = weights.shape
+    heads = np.asarray([l * H + h for l, h in model.alignment_heads], dtype=np.int32)
+    N = n - sot_len - 1
+    mat = np.zeros((N, F), dtype=np.float32)
+    ti = np.zeros(N + F, dtype=np.int32)
+    tj = np.zeros(N + F, dtype=np.int32)
+    plen = C.c_int32(0)
+    model._bind_stream()
+    _lib.check(model._lib.wca_default_find_alignment(model._h, C.c_void_p(weights.data_ptr()), L, H, n, F, heads.ctypes.data_as(_pi),
+                                                     len(heads), sot_len, mat.ctypes.data_as(_pf), ti.ctypes.data_as(_pi),
+                                                     tj.ctypes.data_as(_pi), C.byref(plen)))
+    text_indices = ti[:plen.value].astype(np.int64)
+    time_indices = tj[:plen.value].astype(np.int64)
+    words, word_tokens = tokenizer.split_to_word_tokens(list(text_tokens) + [tokenizer.eot])
+    if len(word_tokens) <= 1:
+        return [[], [], [], [], None]
+    word_boundaries = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
+    jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
+    jump_times = time_indices[jumps] / TOKENS_PER_SECOND
+    return words, jump_times[word_boundaries[:-1]], jump_times[word_boundaries[1:]], torch.from_numpy(mat), None
+
+
 def words_from_jump_frames(jump_frames, tokens, tokenizer, aligned_unit_type="char", want_words=True):
     """Host tail of the fused wca_align_batch path: `jump_frames[i]` is the frame at which the DTW path
     enters text row i (= time_indices[jumps], timing.py:110-111); returns (words, start_times, end_times)
