@@ -33,6 +33,10 @@ for name, n, k, mode in [("qkv", 3072, 1024, 0), ("fc2", 1024, 4096, 2)]:
     nk = k // 64
     for blk in (0, 3):
         for wave in (0, 5):
+            ph = d[blk, wave, 48:60, :2].astype(np.int64)
+            ph = ph[ph[:, 0] > 0]
+            print("%s blk %d wave %d: tiles %d | epilogue issue cycles %s | tile period (epilogue start to next) %s" %
+                  (name, blk, wave, len(ph), (ph[:, 1] - ph[:, 0]).tolist(), np.diff(ph[:, 0]).tolist()))
             s = d[blk, wave, :nk, :5].astype(np.int64)
             seg = np.diff(s, axis=1)  # [half0 mfma+reads, wait vmcnt/lgkm, barrier, half1 (+dma, reads)]
             nxt = s[1:, 0] - s[:-1, 4]

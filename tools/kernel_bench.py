@@ -45,7 +45,7 @@ def main():
         w = (torch.randn(n, k, device="cuda") * 0.05).half()
         bias = torch.randn(n, device="cuda")
         out = torch.zeros(m, n, device="cuda", dtype=torch.float16 if mode == 0 else torch.float32)
-        for tile in (128, 256, 257):
+        for tile in (128, 256, 258, 257):
             if tile >= 256 and m < 2048:
                 continue
             ms = timeit(lambda: wca._lib.check(lib.wca_test_gemm(eng._h, vp(a), vp(w), vp(bias), vp(out), m, n, k, gelu, mode | (tile << 8))))

@@ -332,21 +332,70 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
 
 // Epilogue of the pipelined 256 x 256 kernel (column maps documented at `wsrc_row` there): every store
 // instruction writes 64 contiguous bytes per output row (4 lanes x 16 B).
-template <int OUT_MODE, bool GELU>
-__device__ __forceinline__ void epilogue_wide(const GemmArgs& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg) {
+// ArgsT: GemmArgs, or GemmArgs in the constant address space (the kernarg segment: fields are then re-read with
+// scalar loads where they are used instead of staying live in SGPRs across the caller's K loop).
+template <int OUT_MODE, bool GELU, typename ArgsT>
+__device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg, const float* bias_l) {
   // column of value (nt, r = 0) relative to nbase
   int col[4];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) col[nt] = (OUT_MODE == 0) ? ((nt >> 1) * 32 + fg * 8 + (nt & 1) * 4) : (nt * 16 + fg * 4);
+  // bias_l: this wave's 64 bias values in LDS (zero where there is no bias / past N)
   float bv[16];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt)
+  for (int nt = 0; nt < 4; ++nt) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + col[nt]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = nbase + col[nt] + r;
-      bv[nt * 4 + r] = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
-    }
+    for (int r = 0; r < 4; ++r) bv[nt * 4 + r] = b4[r];
+  }
   const bool full_n = (nbase + 64 <= a.N);
+  if (OUT_MODE == 2) {
+    // read-modify-write of C: the loads of THREE row groups are in flight together (48 VGPRs, free once the K loop
+    // is over); load -> add -> store one row group at a time exposed the full memory latency 8 times per tile
+    // (s_memtime: 31-46 k cycles per tile, 38 % of the attention out-projection's life)
+    float* cbase = reinterpret_cast<float*>(a.C) + nbase;
+    if (full_n && a.pos == nullptr && (a.ldc & 3) == 0 && (a.c_batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(cbase + fg * 4) & 15) == 0)) {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bv[nt * 4 + r];
+      constexpr int NB = 3;  // row groups in flight (4 spills: the K loop's per-lane state stays live in a persistent kernel)
+#pragma unroll
+      for (int base = 0; base < 8; base += NB) {
+        f32x4 cv[NB][4];
+        long coff[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (base + j >= 8) continue;
+          const int m = mbase + (base + j) * 16 + fr;
+          if (a.c_rows_per_batch > 0) {
+            const int b = m / a.c_rows_per_batch;
+            coff[j] = (long)b * a.c_batch_stride + (long)(m - b * a.c_rows_per_batch) * a.ldc;
+          } else {
+            coff[j] = (long)m * a.ldc;
+          }
+          if (m < a.M) {
+            const f32x4* cp = reinterpret_cast<const f32x4*>(cbase + coff[j] + fg * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cv[j][nt] = cp[nt * 4];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          if (base + j >= 8) continue;
+          const int m = mbase + (base + j) * 16 + fr;
+          if (m < a.M) {
+            f32x4* cp = reinterpret_cast<f32x4*>(cbase + coff[j] + fg * 4);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) cp[nt * 4] = acc[base + j][nt] + cv[j][nt];
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
     const int m = mbase + mt * 16 + fr;
@@ -415,23 +464,31 @@ __device__ __forceinline__ void epilogue_wide(const GemmArgs& a, f32x4 (&acc)[8]
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined 256 x 256 x 64 kernel (flat A): ONE barrier per K tile, placed between the two K=32
-// halves. At that point every wave has issued and retired all its ds_reads of the current ring slot
+// Software-pipelined, PERSISTENT 256 x 256 x 64 kernel (flat A): ONE barrier per K tile, placed between the two
+// K=32 halves. At that point every wave has issued and retired all its ds_reads of the current ring slot
 // (fragments of half 1 are fetched while half 0 multiplies), so the barrier is at once
-//   * the WAR guard for refilling this slot with K tile t+2 (DMA issued right after it), and
-//   * the RAW guard for K tile t+1 (each wave's vmcnt(0) precedes the barrier), whose half-0 fragments
+//   * the WAR guard for refilling this slot with K step s+2 (DMA issued right after it), and
+//   * the RAW guard for K step s+1 (each wave's vmcnt(0) precedes the barrier), whose half-0 fragments
 //     are then fetched under the MFMAs of half 1.
+// The K steps of ALL the tiles a workgroup owns (virtual ids blockIdx.x, + gridDim.x, ...; one workgroup per CU)
+// form one continuous stream: the last two K tiles of a tile already fetch K tiles 0 and 1 of the NEXT tile, so a
+// tile's epilogue runs with the next tile's operands in flight and its stores drain under the next tile's
+// MFMAs. (Measured on the one-tile-per-workgroup form with s_memtime stamps: prologue 8 %, epilogue + store
+// drain 15 % of a workgroup's life at K = 1024, nothing overlapping them.)
 // LDS image: [256 rows][64 f16], 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): depends on
 // r & 15 only, so every fragment address is one per-lane base + an immediate. The W rows are PERMUTED AT DMA
 // TIME (which W row lands in LDS row nt*16 + i of each 64-row block depends on the output type, see `wsrc_row`),
 // so that the epilogue's stores are contiguous while both operands are read with natural row order.
 // Operands arrive by LDS-DMA through buffer descriptors: rows past M / N read as zero (no clamping), wave w
 // request i covers tile rows i*64 + w*8 .. +7, so ONE per-lane byte offset per operand suffices.
+// The tile's 256 bias values arrive in LDS by DMA with its first operands: a global load inside the epilogue would
+// have to wait (vmcnt is one in-order counter) for the next tile's operand DMA issued just before it.
 template <int OUT_MODE, bool GELU, int SITE, bool STAMP = false>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
   constexpr int TILE256 = 256 * 64;
+  float* bias_lds = reinterpret_cast<float*>(smem + 4 * TILE256 * sizeof(half_t));  // 2 x 256 floats after the ring
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -440,12 +497,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   const int ntn = (a.N + 255) / 256;
   const int ntm = (a.M + 255) / 256;
   const int nwg = ntm * ntn;
-  const int id = xcd_remap(blockIdx.x, nwg);
-  const int tm = id / ntn, tn = id - tm * ntn;
-  const int m0 = tm * 256, n0 = tn * 256;
+  const int G = gridDim.x;
 
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.A), 0, (int)a.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.W), 0, (int)a.w_bytes, 0x00020000);
+  // bias: 256 floats per tile, double buffered (tile parity), fetched by LDS-DMA with the tile's first operands.
+  // A null bias gives a zero-record descriptor: every lane is out of range and the DMA writes zeros.
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.N * 4 : 0, 0x00020000);
   const int l8 = lane >> 3;
   const int rho = wave * 8 + l8;                       // LDS row (mod 64) this lane fills
   const int c0 = (lane & 7) ^ ((rho >> 1) & 7);        // global chunk that lands at chunk position lane & 7
@@ -455,23 +513,30 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   //   f32 out: lane fg owns columns nt*16 + fg*4 .. +3 (natural)      -> n = nt*16 + i
   const int nt_r = rho >> 4, i_r = rho & 15;
   const int wsrc_row = (OUT_MODE == 0) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
-  const int va = ((m0 + rho) * a.lda + c0 * 8) * 2;
-  const int vw = ((n0 + wsrc_row) * a.ldw + c0 * 8) * 2;
-  const int sa64 = 64 * a.lda * 2, sw64 = 64 * a.ldw * 2;
+  // per-lane byte offsets inside a tile (tile base and K offset are wave-uniform and added per request)
+  const unsigned va = (unsigned)(rho * a.lda + c0 * 8) * 2u;
+  const unsigned vw = (unsigned)(wsrc_row * a.ldw + c0 * 8) * 2u;
+  const unsigned sa64 = 64u * a.lda * 2u, sw64 = 64u * a.ldw * 2u;
 
-  // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each
-  auto stage_one = [&](int buf, int k0, int g) {
+  // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each.
+  // ta / tw: byte offset of (tile row 0, K offset) in A / W.
+  auto stage_one = [&](int buf, unsigned ta, unsigned tw, int g) {
     half_t* At = lds + buf * (2 * TILE256);
     half_t* Wt = At + TILE256;
     const int i = g >> 1;
+    // the wave-uniform part stays an opaque SGPR value: one v_add per request instead of eight per-lane
+    // induction variables (the loop strength reduction otherwise keeps va + i*sa64 + k in 8 VGPRs and spills)
+    unsigned so = ((g & 1) == 0) ? ta + i * sa64 : tw + i * sw64;
+    asm volatile("" : "+s"(so));
     if ((g & 1) == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (WCA_LDS void*)(At + (i * 64 + wave * 8) * 64), 16, va + (i * sa64 + k0 * 2), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (WCA_LDS void*)(At + (i * 64 + wave * 8) * 64), 16, (int)(va + so), 0, 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + wave * 8) * 64), 16, vw + (i * sw64 + k0 * 2), 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + wave * 8) * 64), 16, (int)(vw + so), 0, 0, 0);
   };
-  auto stage = [&](int buf, int k0) {
-#pragma unroll
-    for (int g = 0; g < 8; ++g) stage_one(buf, k0, g);
+
+  auto stage_bias = [&](int par, int ncol0) {
+    if (wave < 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (WCA_LDS void*)(bias_lds + par * 256 + wave * 64), 4, (ncol0 + wave * 64 + lane) * 4, 0, 0, 0);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -485,34 +550,37 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     _Pragma("unroll") for (int t = 0; t < 4; ++t) WF[t] = *reinterpret_cast<const half8*>((WT) + (WB) + t * 1024); \
     _Pragma("unroll") for (int t = 0; t < 8; ++t) XF[t] = *reinterpret_cast<const half8*>((AT) + (XB) + t * 1024); \
   } while (0)
-#define WCA_MFMA_GROUP(WF, XF, LO)                                                                 \
-  do {                                                                                             \
-    _Pragma("unroll") for (int mt = LO; mt < LO + 4; ++mt)                                         \
-      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                             \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[nt], XF[mt], acc[mt][nt], 0, 0, 0); \
-  } while (0)
 
   const int nk = a.K / BK;
   // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
   //  fetch/MFMA orders or different DMA-issue windows to break SIMD-partner lockstep; a software L2 prefetch
-  //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %).)
-  {
-    f32x4 acc[8][4];
+  //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %);
+  //  padding the leading dimensions off a power of two; de-phasing the workgroups' start by up to 1/8 tile.)
+  int v = blockIdx.x;
+  int id = xcd_remap(v, nwg);
+  int m0 = (id / ntn) * 256, n0 = (id % ntn) * 256;
+  unsigned ta = (unsigned)m0 * a.lda * 2u, tw = (unsigned)n0 * a.ldw * 2u;
+
+  f32x4 acc[8][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    half8 w0[4], x0[8], w1[4], x1[8];
-    stage(0, 0);
-    if (nk > 1) {
-      stage(1, BK);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8 w0[4], x0[8], w1[4], x1[8];
+  int par = 0;  // bias buffer of the current tile
+  stage_bias(0, n0);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) stage_one(0, ta, tw, g);
+  if (nk > 1) {
+#pragma unroll
+    for (int g = 0; g < 8; ++g) stage_one(1, ta + BK * 2, tw + BK * 2, g);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
 
 #define WCA_STAMP(IDX)                                                                      \
   do {                                                                                     \
@@ -521,15 +589,22 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       __builtin_amdgcn_sched_barrier(0);                                                   \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
       __builtin_amdgcn_sched_barrier(0);                                                   \
-      if (lane == 0 && blockIdx.x < 4) a.dbg[((blockIdx.x * 8 + wave) * 64 + kt) * 8 + (IDX)] = t_; \
+      if (lane == 0 && blockIdx.x < 4 && v == (int)blockIdx.x) a.dbg[((blockIdx.x * 8 + wave) * 64 + kt) * 8 + (IDX)] = t_; \
     }                                                                                      \
   } while (0)
+  for (;;) {
+    // the tile after this one (persistent launch only: gridDim.x < nwg needs nk even and >= 2, see launch_gemm)
+    const int vn = v + G;
+    const bool has_next = vn < nwg;
+    const int idn = has_next ? xcd_remap(vn, nwg) : id;
+    const int m0n = (idn / ntn) * 256, n0n = (idn % ntn) * 256;
+    const unsigned tan = (unsigned)m0n * a.lda * 2u, twn = (unsigned)n0n * a.ldw * 2u;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
       const half_t* At = lds + cur * (2 * TILE256);
       const half_t* Wt = At + TILE256;
       WCA_STAMP(0);
-      // ---- K half 0 (fragments w0/x0 were fetched under the previous tile's half 1). The 12 fragment reads of
+      // ---- K half 0 (fragments w0/x0 were fetched under the previous step's half 1). The 12 fragment reads of
       // half 1 are issued two at a time between groups of 4 MFMAs.
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
@@ -548,17 +623,20 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(1);
-      // all ds_reads of slot `cur` are retired; K tile kt+1 (the only DMA in flight) has landed
+      // all ds_reads of slot `cur` are retired; K step s+1 (the only DMA in flight) has landed
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       WCA_STAMP(3);
-      // ---- K half 1. Slot `cur` is refilled with tile kt+2 and tile kt+1's half-0 fragments are fetched, ONE
-      // DMA request and up to two ds_reads per group of 4 MFMAs: 64 back-to-back requests per CU right after the
-      // barrier serialise in the memory pipe and delay the MFMAs of the waves that issue last (measured with
-      // s_memtime stamps: ~1000 cycles of barrier skew per K tile).
-      const bool more1 = kt + 1 < nk, more2 = kt + 2 < nk;
+      // ---- K half 1. Slot `cur` is refilled with K step s+2 (of this tile, or of the next one) and step s+1's
+      // half-0 fragments are fetched (within a tile), ONE DMA request and up to two ds_reads per group of 4 MFMAs: 64 back-to-back
+      // requests per CU right after the barrier serialise in the memory pipe and delay the MFMAs of the waves that
+      // issue last (measured with s_memtime stamps: ~1000 cycles of barrier skew per K tile).
+      const bool in_tile2 = kt + 2 < nk;
+      const bool more1 = kt + 1 < nk, more2 = in_tile2 || has_next;
+      const unsigned ka = (in_tile2 ? ta + (unsigned)(kt + 2) * (BK * 2) : tan + (unsigned)(kt + 2 - nk) * (BK * 2));
+      const unsigned kw = (in_tile2 ? tw + (unsigned)(kt + 2) * (BK * 2) : twn + (unsigned)(kt + 2 - nk) * (BK * 2));
       const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
       const half_t* Wn = An + TILE256;
 #pragma unroll
@@ -568,7 +646,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) stage_one(cur, (kt + 2) * BK, g);
+        if (more2) stage_one(cur, ka, kw, g);
         if (more1) {
           if (g < 2) {
             w0[2 * g] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g) * 1024);
@@ -582,13 +660,45 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       }
       WCA_STAMP(4);
     }
-#undef WCA_STAMP
-    epilogue_wide<OUT_MODE, GELU>(a, acc, m0 + wr * 128, n0 + wc * 64, fr, fg);
+
+    if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
+      a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 0] = __builtin_readcyclecounter();
+    {
+      // opaque copies: keeps the epilogue's per-lane address arithmetic from being hoisted out of the tile loop
+      // (live across the K loop it cost 30 VGPRs and spilled)
+      int fr_e = fr, fg_e = fg;
+      asm volatile("" : "+v"(fr_e), "+v"(fg_e));
+      // the epilogue re-reads its arguments from the kernarg segment (scalar loads) instead of keeping ~20 SGPRs
+      // of GemmArgs live across the K loop, where they spilled into VGPR lanes
+      typedef __attribute__((address_space(4))) GemmArgs KernArgs;
+      const KernArgs* ap = (const KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ap));
+      epilogue_wide<OUT_MODE, GELU, KernArgs>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64);
+    }
+    if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
+      a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 1] = __builtin_readcyclecounter();
+    if (!has_next) break;
+    // next tile's bias -> the other buffer: its last readers (the epilogue two tiles back) are behind at least one
+    // barrier, and the first mid-tile barrier of the new tile (vmcnt(0) on every wave) makes it visible
+    par ^= 1;
+    stage_bias(par, n0n);
+    v = vn;
+    id = idn;
+    m0 = m0n;
+    n0 = n0n;
+    ta = tan;
+    tw = twn;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // K tile 0 of the new tile landed before the last mid-tile barrier; its fragments are fetched only now so
+    // that they are not live across the epilogue (that cost 13-18 spilled VGPRs)
+    WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
   }
-#undef WCA_MFMA_GROUP
+#undef WCA_STAMP
 #undef WCA_LOAD_HALF
 }
-
 
 }  // namespace
 
@@ -603,7 +713,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
   if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
   if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
-  const bool want_big = (a.force_tile == 256 || a.force_tile == 257) || (a.force_tile == 0 && tiles256 >= 192);
+  const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
   dim3 grid, block;
@@ -612,6 +722,20 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     grid = dim3((unsigned)tiles256);
     block = dim3(512);
     shmem = 2 * 2 * 256 * 64 * sizeof(half_t);  // 128 KiB
+    if (pipelined) {
+      shmem += 2 * 256 * sizeof(float);  // the tile's bias values, double buffered
+      // persistent: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... (the ring-slot parity carries
+      // over a tile boundary only for an even number of K tiles); force_tile 258 = one tile per workgroup
+      static int n_cu = 0;
+      if (n_cu == 0) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+      }
+      const int nk = a.K / BK;
+      if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
+    }
   } else {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     grid = dim3(ntn * ntm);
