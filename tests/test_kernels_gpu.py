@@ -58,6 +58,39 @@ def test_gemm(eng, lib, wca, M, N, K, mode, tile):
         torch.testing.assert_close(out.cpu(), base + ref, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
+@pytest.mark.parametrize("tile", [257])
+@pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024)])
+def test_gemm_persistent_many_tiles(eng, lib, wca, M, N, K, mode, tile):
+    """More 256x256 tiles than CUs: a workgroup walks several tiles, its operand stream, bias buffers and ring-slot
+    parity carry across tile boundaries (ragged M and N in the first shape). Reference: fp32 matmul of the same
+    f16 operands on the GPU; tolerances = f16 output rounding (2^-11) resp. fp32 accumulation order."""
+    g = torch.Generator().manual_seed(M + N + K)
+    ad = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    wd = (torch.randn(N, K, generator=g) * 0.1).half().cuda()
+    bd = torch.randn(N, generator=g).cuda()
+    ref = ad.float() @ wd.float().T + bd
+    if mode in ("f16", "f16_gelu"):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        gelu = int(mode == "f16_gelu")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0 | (tile << 8)))
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+    elif mode == "f32":
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 1 | (tile << 8)))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-4)
+    else:
+        base = torch.randn(M, N, generator=g).cuda()
+        out = base.clone()
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2 | (tile << 8)))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, base + ref, rtol=2e-4, atol=2e-4)
+
+
 @pytest.mark.parametrize("M,N,K", [(2000, 768, 1024), (515, 1024, 4096), (4096, 256, 64)])
 def test_gemm_256_tile_long_k_and_tails(eng, lib, wca, M, N, K):
     """The 256x256 kernel's DMA ring (prefetch distance 2, counted vmcnt) over many K tiles and ragged M."""

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwca.so")
 SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "engine.hip"]
-HEADERS = ["kernels.h", "wca_common.h", os.path.join("..", "..", "include", "wca.h")]
+HEADERS = ["kernels.h", "wca_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "wca.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (the softmax / epilogue VALU code reads them
 # directly; the AGPR form costs a v_accvgpr_read/write pair per element in the attention loop)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -1468,7 +1468,7 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, 
   g.M = M;
   g.N = N;
   g.K = K;
-  g.out_mode = out_mode;
+  g.out_mode = out_mode & 0xff;
   g.force_tile = 257;
   g.dbg = dbg_dev;
   HIPCHK(launch_gemm(g, e->stream));

@@ -11,6 +11,7 @@
 // The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
 // W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
 // of one output row: the epilogue stores 32 B (f16) / 64 B (f32) per lane per row.
+#include "gemm_epilogue.h"
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -332,137 +333,6 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
 
 // Epilogue of the pipelined 256 x 256 kernel (column maps documented at `wsrc_row` there): every store
 // instruction writes 64 contiguous bytes per output row (4 lanes x 16 B).
-// ArgsT: GemmArgs, or GemmArgs in the constant address space (the kernarg segment: fields are then re-read with
-// scalar loads where they are used instead of staying live in SGPRs across the caller's K loop).
-template <int OUT_MODE, bool GELU, typename ArgsT>
-__device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg, const float* bias_l) {
-  // column of value (nt, r = 0) relative to nbase
-  int col[4];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) col[nt] = (OUT_MODE == 0) ? ((nt >> 1) * 32 + fg * 8 + (nt & 1) * 4) : (nt * 16 + fg * 4);
-  // bias_l: this wave's 64 bias values in LDS (zero where there is no bias / past N)
-  float bv[16];
-#pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + col[nt]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) bv[nt * 4 + r] = b4[r];
-  }
-  const bool full_n = (nbase + 64 <= a.N);
-  if (OUT_MODE == 2) {
-    // read-modify-write of C: the loads of THREE row groups are in flight together (48 VGPRs, free once the K loop
-    // is over); load -> add -> store one row group at a time exposed the full memory latency 8 times per tile
-    // (s_memtime: 31-46 k cycles per tile, 38 % of the attention out-projection's life)
-    float* cbase = reinterpret_cast<float*>(a.C) + nbase;
-    if (full_n && a.pos == nullptr && (a.ldc & 3) == 0 && (a.c_batch_stride & 3) == 0 && ((reinterpret_cast<uintptr_t>(cbase + fg * 4) & 15) == 0)) {
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bv[nt * 4 + r];
-      constexpr int NB = 3;  // row groups in flight (4 spills: the K loop's per-lane state stays live in a persistent kernel)
-#pragma unroll
-      for (int base = 0; base < 8; base += NB) {
-        f32x4 cv[NB][4];
-        long coff[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          if (base + j >= 8) continue;
-          const int m = mbase + (base + j) * 16 + fr;
-          if (a.c_rows_per_batch > 0) {
-            const int b = m / a.c_rows_per_batch;
-            coff[j] = (long)b * a.c_batch_stride + (long)(m - b * a.c_rows_per_batch) * a.ldc;
-          } else {
-            coff[j] = (long)m * a.ldc;
-          }
-          if (m < a.M) {
-            const f32x4* cp = reinterpret_cast<const f32x4*>(cbase + coff[j] + fg * 4);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cv[j][nt] = cp[nt * 4];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          if (base + j >= 8) continue;
-          const int m = mbase + (base + j) * 16 + fr;
-          if (m < a.M) {
-            f32x4* cp = reinterpret_cast<f32x4*>(cbase + coff[j] + fg * 4);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) cp[nt * 4] = acc[base + j][nt] + cv[j][nt];
-          }
-        }
-      }
-      return;
-    }
-  }
-#pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int m = mbase + mt * 16 + fr;
-    float v[16];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
-    if (m >= a.M) continue;
-    if (GELU) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
-    }
-    if (a.pos != nullptr) {
-      const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nbase;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (nbase + col[nt] + r < a.N) v[nt * 4 + r] += pp[col[nt] + r];
-    }
-    long coff;
-    if (a.c_rows_per_batch > 0) {
-      const int b = m / a.c_rows_per_batch;
-      const int t = m - b * a.c_rows_per_batch;
-      coff = (long)b * a.c_batch_stride + (long)t * a.ldc;
-    } else {
-      coff = (long)m * a.ldc;
-    }
-    if (OUT_MODE == 0) {
-      half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nbase;
-      if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 8) & 15) == 0)) {
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          half8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[hh * 8 + j];
-          *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nbase + col[nt] + r < a.N) cp[col[nt] + r] = (half_t)v[nt * 4 + r];
-      }
-    } else {
-      float* cp = reinterpret_cast<float*>(a.C) + coff + nbase;
-      if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 4) & 15) == 0)) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          f32x4* c4 = reinterpret_cast<f32x4*>(cp + col[nt]);
-          f32x4 o = f32x4{v[nt * 4 + 0], v[nt * 4 + 1], v[nt * 4 + 2], v[nt * 4 + 3]};
-          if (OUT_MODE == 2) o += *c4;
-          *c4 = o;
-        }
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (nbase + col[nt] + r < a.N) cp[col[nt] + r] = (OUT_MODE == 2) ? cp[col[nt] + r] + v[nt * 4 + r] : v[nt * 4 + r];
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Software-pipelined, PERSISTENT 256 x 256 x 64 kernel (flat A): ONE barrier per K tile, placed between the two
 // K=32 halves. At that point every wave has issued and retired all its ds_reads of the current ring slot
@@ -555,7 +425,15 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
   //  fetch/MFMA orders or different DMA-issue windows to break SIMD-partner lockstep; a software L2 prefetch
   //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %);
-  //  padding the leading dimensions off a power of two; de-phasing the workgroups' start by up to 1/8 tile.)
+  //  padding the leading dimensions off a power of two; de-phasing the workgroups' start by up to 1/8 tile.
+  //  Two re-designs around a ring of FOUR K=32 slots (64-byte LDS rows, chunk ^ ((r>>1)&3), DMA four steps ahead,
+  //  counted vmcnt, one barrier per K=32 step), both parity-green, neither faster in the pipeline:
+  //   * four waves, one per SIMD, 128x128 per wave with the 256 accumulators in AGPRs (inline-asm in-place MFMA):
+  //     s_memtime shows 1316-1400 cycles per 64-MFMA step against 1024 for the MFMAs alone -- a wave's own
+  //     ds_read / DMA / SALU instructions do not issue underneath its MFMAs, only another wave's do; QKV +8 %,
+  //     fc1 -6 %, fc2 -11 % (each wave runs twice the epilogue), bench unchanged;
+  //   * eight waves on the same ring: QKV +14 % in isolation (operands L2 resident), cross-KV -5 %, fc2 -4 %
+  //     (64-byte DMA segments on operands that miss L2), bench unchanged.)
   int v = blockIdx.x;
   int id = xcd_remap(v, nwg);
   int m0 = (id / ntn) * 256, n0 = (id % ntn) * 256;
@@ -713,6 +591,13 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
   if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
   if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+  }
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
@@ -726,13 +611,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       shmem += 2 * 256 * sizeof(float);  // the tile's bias values, double buffered
       // persistent: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... (the ring-slot parity carries
       // over a tile boundary only for an even number of K tiles); force_tile 258 = one tile per workgroup
-      static int n_cu = 0;
-      if (n_cu == 0) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e != hipSuccess) return e;
-      }
       const int nk = a.K / BK;
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
     }
