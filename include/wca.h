@@ -20,6 +20,10 @@
  *   wca_default_find_alignment  timing.py:116-186 default_find_alignment (std/mean normalised alignment heads)
  *   wca_dtw                timing.py:103     whisper.timing.dtw -> dtw_cpu + backtrace
  *   wca_probe_heads        probe_oracle.py:83-90  per-head force_align sweep (one DTW per head)
+ *   wca_greedy_decode      infer_ali.py:40,60-61, probe_oracle.py:59-60, README.md:107-108:
+ *                          whisper.decode(model, mels, DecodingOptions(language="en")) -- the greedy ASR pre-pass
+ *                          that produces the teacher text (upstream decoding.py: KV-cached autoregressive
+ *                          decoder, SuppressBlank / SuppressTokens / ApplyTimestampRules, GreedyDecoder)
  *   wca_align_batch        infer_ali.py:93-101 + dataset.py:47-48: the whole per-utterance pipeline
  *                          (log-mel -> forward+capture -> medfilt/softmax -> scores/top-k ->
  *                          aggregate -> DTW) for a micro-batch of utterances, results = the frame
@@ -157,8 +161,8 @@ int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int
                     int32_t* jump_frame_host);
 
 /* Fused per-utterance pipeline for a micro-batch (the north-star hot path).
- * pcm_dev [batch][pcm_stride] f32; tokens_dev [batch][n_tok_max] int64; n_tok_host, n_samples_host,
- * max_frames_host [batch].
+ * pcm_dev [batch][pcm_stride] f32 (NULL: re-use the encoder state of the preceding wca_greedy_decode of this
+ * batch); tokens_dev [batch][n_tok_max] int64; n_tok_host, n_samples_host, max_frames_host [batch].
  * jump_frame_host [batch][n_tok_max]: for utterance b, entries [0, n_tok[b] - sot_len - 1) are the frame
  * index at which the DTW path enters that text row (jump_times * 50, timing.py:110-111).
  * sel_idx_host [batch][topk] may be NULL. */
@@ -166,6 +170,34 @@ int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, con
                     const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host,
                     const int32_t* max_frames_host, int batch, const wca_align_opts* opts, int32_t* jump_frame_host,
                     int32_t* sel_idx_host);
+
+/* whisper.DecodingOptions as the reference uses it (infer_ali.py:40: language="en", everything else default:
+ * task transcribe, temperature 0 -> greedy, no beam, sample_len n_text_ctx // 2, suppress_blank, suppress_tokens "-1",
+ * without_timestamps False, max_initial_timestamp 1.0, no prompt / prefix). */
+typedef struct {
+  int32_t sample_len;                  /* maximum number of sampled tokens (224)                              */
+  int32_t eot;                         /* tokenizer.eot                                                       */
+  int32_t timestamp_begin;             /* tokenizer.timestamp_begin (<|0.00|>)                                */
+  int32_t apply_timestamp_rules;       /* 1 = ApplyTimestampRules (without_timestamps False)                  */
+  int32_t max_initial_timestamp_index; /* round(max_initial_timestamp / 0.02) = 50; < 0 = no limit            */
+} wca_decode_opts;
+
+/* Greedy ASR pre-pass for a micro-batch. Exactly one of mel_dev ([batch][n_mels][3000] f32, what whisper.decode
+ * takes) and pcm_dev ([batch][pcm_stride] f32 + n_samples_host, log-mel computed on the device) is non-NULL.
+ * initial_tokens_host [n_initial]: tokenizer.sot_sequence (every row starts with it).
+ * suppress_mask_host [n_vocab] bytes: 1 = logit forced to -inf at every step (SuppressTokens list and, when the
+ *   timestamp rules are on, <|notimestamps|>); blank_mask_host [n_vocab] (nullable): 1 = -inf at the first sampled
+ *   position (SuppressBlank: tokenizer.encode(" ") + [eot]).
+ * tokens_out_host [batch][n_initial + sample_len] int32 (positions never reached hold eot);
+ * n_tokens_host [batch]: row b's sampled tokens before its first EOT are tokens_out[b][n_initial : n_tokens[b]];
+ * sum_logprob_host [batch] (nullable): GreedyDecoder's sum of log-probabilities of the sampled tokens.
+ * The encoder output and cross-attention K/V of this batch stay in the engine: the next wca_align_batch_enqueue
+ * for the same batch may pass pcm_dev = NULL to re-use them (the reference runs the encoder twice,
+ * infer_ali.py:60 and timing.py:58). Synchronous; no wca_align_batch_enqueue may be pending. */
+int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride,
+                      const int32_t* n_samples_host, int batch, const int32_t* initial_tokens_host, int n_initial,
+                      const uint8_t* suppress_mask_host, const uint8_t* blank_mask_host, const wca_decode_opts* opts,
+                      int32_t* tokens_out_host, int32_t* n_tokens_host, float* sum_logprob_host);
 
 /* Same pipeline, but only enqueues the work on the engine stream (no host sync; results stay in the engine's
  * pinned staging ring until wca_align_batch_fetch). Up to TWO batches may be in flight: _fetch returns the
@@ -191,6 +223,10 @@ int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, cons
 /* diagnostic build with s_memtime stamps per key tile ([4 blocks][4 waves][32 tiles][8] u64); tools/attn_stamps.py */
 int wca_test_attention_stamped(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev, int B, int H,
                                int nq, int nk, unsigned long long* dbg_dev);
+/* one step of the greedy decoder's filters + update on caller-supplied logits (kernel parity test) */
+int wca_test_decode_select(wca_engine* e, const float* logits_dev, int batch, int n_vocab, int32_t* tokens_dev, int T_max,
+                           int cur_len, int n_initial, const uint8_t* suppress_mask_dev, const uint8_t* blank_mask_dev,
+                           const wca_decode_opts* opts, float* sum_logprob_dev, int32_t* n_done_dev);
 int wca_test_layernorm(wca_engine* e, const float* x_dev, const float* g_dev, const float* b_dev, void* out_f16_dev,
                        int rows, int d);
 /* encoder only: mel_dev [batch][n_mels][3000] f32 -> xa_out_dev [batch][1500][d] f32 (ln_post output) */

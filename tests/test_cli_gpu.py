@@ -66,6 +66,30 @@ def test_infer_ali_and_eval_ali(corpus, capsys):
     assert abs(r["precision"] - res["precision"]) < 1e-9 and abs(r["recall"] - res["recall"]) < 1e-9
 
 
+def test_infer_ali_teacher_asr(corpus, fake_vocab, capsys):
+    """The reference's own flow (infer_ali.py:60-68): greedy ASR pre-pass -> remove_punctuation -> char tokens -> alignment
+    re-using the encoder state. Random weights give a meaningless hypothesis; this checks the plumbing end to end
+    (every utterance is either aligned with monotone word times or reported as skipped)."""
+    root, scp = corpus
+    infer = _m("infer_ali")
+    out = root / "out_asr"
+    args = infer.parse_args(["--model", "tiny", "--random_init", "--dataset", "TIMIT", "--scp", str(scp), "--output_dir", str(out),
+                             "--aggr", "topk", "--topk", "5", "--aligned_unit_type", "char", "--medfilt_width", "3", "--batch_size", "2",
+                             "--save_prediction", "--tolerance", "0.05", "--teacher", "asr", "--vocab", fake_vocab])
+    infer.infer_dataset(args)
+    js = glob.glob(str(out / "*.json"))
+    assert len(js) == 1
+    res = json.load(open(js[0]))
+    assert res["teacher"] == "asr" and "f1" in res
+    import joblib
+    preds = joblib.load(glob.glob(str(out / "*-predictions.pkl"))[0])
+    printed = capsys.readouterr().out
+    for u in range(5):
+        assert u in preds or ("utt%d" % u) in printed
+    for p in preds.values():
+        assert np.all(np.diff(p["ends_hat"]) >= 0)
+
+
 def test_probe_heads_matches_per_head_force_align(wca):
     """wca_probe_heads == force_align(w[l,h][None,None], aggregation='mean') for every head (probe_oracle.py:88-90)."""
     tm, tk, probe = _m("timing"), _m("tokenizer"), _m("probe_oracle")

@@ -1,0 +1,191 @@
+"""Greedy ASR pre-pass (reference infer_ali.py:40,60-61 `whisper.decode(..., DecodingOptions(language="en"))`)
+on the MI355X, through the C ABI, against the CPU oracle (oracle/decoding_ref.py, a restatement of upstream decoding.py).
+
+  * the per-step filter + greedy-update kernel is integer / index work on given fp32 logits: BIT-EXACT token choice,
+    EOT latching and completion counts; the accumulated log-probability within 1e-4 (fp32 log-sum-exp order);
+  * the full loop (encoder + KV-cached decoder in f16 operands / fp32 accumulate vs the fp32 oracle) cannot be
+    token-exact by construction when two logits are closer than the f16 noise, so it is scored step by step: the
+    oracle is teacher-forced along the GPU's tokens and every GPU choice must (a) never be a token the oracle's
+    filters removed and (b) be the oracle's argmax, or lose to it by less than the stated logit tolerance.
+"""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+dref = importlib.import_module("oracle.decoding_ref")
+wref = importlib.import_module("oracle.whisper_ref")
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("whisper-char-alignment_amd")
+
+
+@pytest.fixture(scope="module")
+def small(pkg):
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    # tiny model, but the real multilingual vocabulary size so that every special-token id is meaningful
+    dims = pkg.ModelDimensions(80, 1500, 256, 4, 2, 51865, 448, 256, 4, 2)
+    sd = syn.random_state_dict(dims, seed=5)
+    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=4)
+    m.load_state_dict(sd)
+    return m, sd, dims
+
+
+def _setup(pkg, dims, without_timestamps=False):
+    decoding = importlib.import_module("whisper-char-alignment_amd.decoding")
+    tokmod = importlib.import_module("whisper-char-alignment_amd.tokenizer")
+    tok = tokmod.get_tokenizer(True, language="en", task="transcribe")
+    opts = decoding.DecodingOptions(language="en", without_timestamps=without_timestamps)
+    sup, blank = decoding.filter_masks(tok, opts, dims.n_vocab)
+    return decoding, tok, opts, sup, blank
+
+
+@pytest.mark.parametrize("case", ["first", "text", "after_single_ts", "after_ts_pair", "ts_mass_wins", "finished_row", "no_ts_rules"])
+def test_select_kernel_bit_exact(pkg, small, case):
+    m, _, dims = small
+    lib = m._lib
+    _lib = importlib.import_module("whisper-char-alignment_amd._lib")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims, without_timestamps=(case == "no_ts_rules"))
+    V, B, T_max = dims.n_vocab, 4, 40
+    tsb, eot = tok.timestamp_begin, tok.eot
+    initial = list(tok.sot_sequence) + ([tok.no_timestamps] if case == "no_ts_rules" else [])
+    n_init = len(initial)
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    logits = torch.randn(B, V, generator=g) * 3.0
+    hist = {
+        "first": [],
+        "no_ts_rules": [],
+        "text": [tsb + 3, 400, 500],
+        "after_single_ts": [tsb + 3, 400, 500, tsb + 10],
+        "after_ts_pair": [tsb + 3, 400, tsb + 10, tsb + 10],
+        "ts_mass_wins": [tsb + 3, 400, 500],
+        "finished_row": [tsb + 3, 400, 500],
+    }[case]
+    rows = [list(initial) + list(hist) for _ in range(B)]
+    if case == "finished_row":
+        rows[1][-1] = eot  # row 1 already ended
+        rows[2] = list(initial) + [tsb + 3, 400, eot]
+    if case == "ts_mass_wins":
+        logits[:, tsb:] += 4.0  # many moderately likely timestamps outweigh the best text token
+    if case == "first":
+        logits[0, tsb + 70] = 50.0  # beyond max_initial_timestamp: must not be chosen
+        logits[1, 300] = 50.0       # text at the first position: must not be chosen
+    cur_len = len(rows[0])
+    tokens = torch.full((B, T_max), eot, dtype=torch.int32)
+    for b in range(B):
+        tokens[b, :cur_len] = torch.tensor(rows[b], dtype=torch.int32)
+    # ---- oracle
+    filters = dref.make_filters(n_init, eot, tsb, tok.no_timestamps, [i for i in np.nonzero(sup)[0] if i != tok.no_timestamps],
+                                tok.encode(" "), apply_timestamp_rules=(case != "no_ts_rules"),
+                                max_initial_timestamp_index=50)
+    otok = torch.tensor(rows, dtype=torch.long)
+    osum = torch.zeros(B)
+    otok2, completed, _ = dref.select_step(logits, otok, osum, filters, eot)
+    # ---- GPU kernel
+    ld, td = logits.cuda(), tokens.cuda()
+    supd = torch.from_numpy(sup).cuda()
+    blankd = torch.from_numpy(blank).cuda()
+    lpd = torch.zeros(B, device="cuda")
+    nd = torch.zeros(T_max, dtype=torch.int32, device="cuda")
+    o = _lib.DecodeOpts(224, eot, tsb, 0 if case == "no_ts_rules" else 1, 50)
+    m._bind_stream()
+    _lib.check(lib.wca_test_decode_select(m._h, _vp(ld), B, V, _vp(td), T_max, cur_len, n_init, _vp(supd), _vp(blankd), C.byref(o),
+                                          _vp(lpd), _vp(nd)))
+    torch.cuda.synchronize()
+    got = td.cpu()[:, cur_len].long()
+    assert torch.equal(got, otok2[:, -1]), (case, got, otok2[:, -1])
+    assert int(nd.cpu()[cur_len]) == int((otok2[:, -1] == eot).sum())
+    torch.testing.assert_close(lpd.cpu(), osum, rtol=1e-4, atol=1e-4)
+    if case == "first":
+        assert (got >= tsb).all() and (got <= tsb + 50).all()
+
+
+def test_greedy_decode_vs_oracle(pkg, small):
+    m, sd, dims = small
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims)
+    B, sample_len = 3, 12
+    pcm = np.stack([syn.synth_audio(b, n_samples=48000) for b in range(B)])
+    mel = torch.stack([audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=m) for p in pcm]).cuda()
+    initial = list(tok.sot_sequence)
+    toks, n_tok, lps = m.greedy_decode(mel, None, None, initial, sup, blank, sample_len=sample_len, eot=tok.eot,
+                                       timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50)
+    assert toks.shape == (B, len(initial) + sample_len)
+    assert (toks[:, :len(initial)] == np.array(initial)).all()
+    # ---- oracle, teacher-forced along the GPU's choices
+    ref = wref.WhisperRef({k: v.float() for k, v in sd.items()}, dims)
+    filters = dref.make_filters(len(initial), tok.eot, tok.timestamp_begin, tok.no_timestamps,
+                                [i for i in np.nonzero(sup)[0] if i != tok.no_timestamps], tok.encode(" "), True, 50)
+    forced = torch.from_numpy(toks.astype(np.int64))
+    _, _, per_step = dref.greedy_decode(ref, mel.cpu(), initial, filters, tok.eot, sample_len, forced=forced)
+    n_exact = n_total = 0
+    tol = 0.05  # logits are O(1); f16 operands in a 2-layer model perturb them by ~1e-2
+    for i, filt in enumerate(per_step):
+        pos = len(initial) + i
+        if pos >= toks.shape[1]:
+            break
+        for b in range(B):
+            if i > 0 and toks[b, pos - 1] == tok.eot:
+                assert toks[b, pos] == tok.eot  # EOT latches
+                continue
+            choice = int(toks[b, pos])
+            assert torch.isfinite(filt[b, choice]), "GPU chose a token the oracle's filters removed (step %d row %d: %d)" % (i, b, choice)
+            best = float(filt[b].max())
+            assert float(filt[b, choice]) >= best - tol, (i, b, choice, float(filt[b, choice]), best)
+            n_total += 1
+            n_exact += int(choice == int(filt[b].argmax()))
+    assert n_total >= B * 3
+    assert n_exact >= 0.8 * n_total  # the bulk of the steps agree exactly
+    # first sampled token is a timestamp <= 1.00 s, and timestamps never decrease
+    assert ((toks[:, len(initial)] >= tok.timestamp_begin) & (toks[:, len(initial)] <= tok.timestamp_begin + 50)).all()
+    for b in range(B):
+        ts = [t for t in toks[b, len(initial):n_tok[b]] if t >= tok.timestamp_begin]
+        assert all(x <= y for x, y in zip(ts, ts[1:]))
+
+
+def test_decode_api_and_encoder_reuse(pkg, small, fake_vocab):
+    """whisper.decode mirror + the alignment that follows re-uses the encoder state (pcm=None) and gives the same
+    jump frames as a from-scratch align_batch on the same tokens."""
+    m, sd, dims = small
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims)
+    B = 2
+    pcm = np.stack([syn.synth_audio(10 + b, n_samples=64000) for b in range(B)]).astype(np.float32)
+    pcm_d = torch.from_numpy(pcm).cuda()
+    n_samples = [64000] * B
+    res = decoding.decode(m, None, decoding.DecodingOptions(language="en", sample_len=8, vocab_path=fake_vocab), pcm=pcm_d,
+                          n_samples=n_samples)
+    assert len(res) == B and all(isinstance(r.text, str) for r in res)
+    assert all(len(r.tokens) <= 8 for r in res)
+    text_tokens = [tok.encode(c)[0] for c in "ab cd"]
+    row = [*tok.sot_sequence, tok.no_timestamps, *text_tokens, tok.eot]
+    tokens = torch.tensor([row] * B, dtype=torch.int64, device="cuda")
+    o = m.make_opts(aggregation="topk", topk=3, sot_len=len(tok.sot_sequence), medfilt_width=3)
+    jump_reuse, _ = m.align_batch(None, None, tokens, [len(row)] * B, [200] * B, o)
+    jump_fresh, _ = m.align_batch(pcm_d, n_samples, tokens, [len(row)] * B, [200] * B, o)
+    assert np.array_equal(jump_reuse, jump_fresh)
+    with pytest.raises(Exception):
+        m.align_batch(None, None, tokens, [len(row)] * B, [200] * B, o)  # the state was consumed
+
+
+def test_decode_rejects_unsupported(pkg, small):
+    m, _, dims = small
+    decoding = importlib.import_module("whisper-char-alignment_amd.decoding")
+    mel = torch.zeros(1, 80, 3000, device="cuda")
+    with pytest.raises(NotImplementedError):
+        decoding.decode(m, mel, decoding.DecodingOptions(language="en", beam_size=5))
+    with pytest.raises(NotImplementedError):
+        decoding.decode(m, mel, decoding.DecodingOptions(language=None))
+    with pytest.raises(NotImplementedError):
+        decoding.decode(m, mel, decoding.DecodingOptions(language="en", temperature=0.2))

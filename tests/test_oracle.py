@@ -246,3 +246,62 @@ def test_log_mel_matches_hf_feature_extractor():
     ours = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), audio.mel_filters(80)).numpy()
     assert hf.shape == ours.shape == (80, 3000)
     assert np.abs(hf - ours).max() < 1e-4
+
+
+# ------------------------------------------------------------------ greedy decode restatement (oracle/decoding_ref.py)
+def _dref():
+    import importlib
+    return importlib.import_module("oracle.decoding_ref")
+
+
+def test_decoding_ref_timestamp_rules_known_answers():
+    """Hand-derived cases on a 12-token vocabulary: text 0..4, eot 5, specials 6..7 (7 = <|notimestamps|>), timestamps 8..11."""
+    d = _dref()
+    import numpy as np
+    import torch
+    TS, EOT, NOTS, SB = 8, 5, 7, 2
+    rules = d.ApplyTimestampRules(TS, EOT, NOTS, SB, max_initial_timestamp_index=1)
+    inf = float("inf")
+    # (1) first sampled position: only timestamps 8..9 (<= begin + 1) survive
+    lg = torch.zeros(1, 12)
+    rules.apply(lg, torch.tensor([[0, 1]]))
+    assert lg[0].tolist() == [-inf] * 8 + [0.0, 0.0] + [-inf] * 2
+    # (2) after a single timestamp (text before it): no text < eot; timestamps may repeat (closing the segment) but not decrease
+    lg = torch.zeros(1, 12)
+    lg[0, EOT] = 5.0  # keep the text part's max above the timestamp mass so that the last rule does not fire
+    rules.apply(lg, torch.tensor([[0, 1, 9, 3, 10]]))
+    assert lg[0].tolist() == [-inf] * 5 + [5.0, 0.0, -inf] + [-inf, -inf, 0.0, 0.0]
+    # (3) after a timestamp PAIR: no timestamp at all; text is free; earlier timestamps stay forbidden anyway
+    lg = torch.zeros(1, 12)
+    rules.apply(lg, torch.tensor([[0, 1, 9, 3, 10, 10]]))
+    assert lg[0].tolist() == [0.0] * 7 + [-inf] + [-inf] * 4
+    # (4) probability mass: three timestamps at 0 outweigh a best text token at 1.0 (log 3 > 1.0) -> text removed;
+    #     at 1.2 they do not (log 3 < 1.2)
+    for top, removed in ((1.0, True), (1.2, False)):
+        lg = torch.full((1, 12), -30.0)
+        lg[0, 2] = top
+        lg[0, 9:12] = 0.0
+        rules.apply(lg, torch.tensor([[0, 1, 8, 3]]))  # history: ts 8 then text -> timestamps >= 9 allowed
+        assert (lg[0, 2] == -inf) == removed
+        assert lg[0, 8] == -inf and lg[0, 9] == 0.0
+
+
+def test_decoding_ref_greedy_update_and_blank():
+    d = _dref()
+    import torch
+    EOT = 5
+    tokens = torch.tensor([[0, 1, 3], [0, 1, EOT]])
+    lg = torch.tensor([[0.0, 2.0, 0.0, 0.0, 0.0, 1.0], [9.0, 0.0, 0.0, 0.0, 0.0, 0.0]])
+    s = torch.zeros(2)
+    t2, completed = d.greedy_update(tokens, lg, s, EOT)
+    assert t2[:, -1].tolist() == [1, EOT] and not completed  # a finished row keeps emitting EOT
+    assert abs(float(s[0]) - float(torch.log_softmax(lg[0], -1)[1])) < 1e-6 and float(s[1]) == 0.0  # and stops accumulating
+    t3, completed = d.greedy_update(torch.tensor([[0, EOT], [0, EOT]]), lg, torch.zeros(2), EOT)
+    assert completed
+    sb = d.SuppressBlank([2], EOT, sample_begin=2)
+    lg = torch.zeros(1, 6)
+    sb.apply(lg, torch.tensor([[0, 1]]))
+    assert lg[0].tolist() == [0.0, 0.0, float("-inf"), 0.0, 0.0, float("-inf")]
+    lg = torch.zeros(1, 6)
+    sb.apply(lg, torch.tensor([[0, 1, 3]]))  # only at the first sampled position
+    assert lg.abs().sum() == 0

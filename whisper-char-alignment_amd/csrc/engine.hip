@@ -148,6 +148,10 @@ struct wca_engine {
 
   // ---- run-time sized buffers
   GrowBuf cap, wws, colnorm, scores, sel, selsc, matrix, trace, path, pathlen, jump, tmp0, tmp1;
+  // greedy ASR pre-pass (wca_greedy_decode): self-attention K/V cache [L][2][B][T_max][d], token rows, masks, logits
+  GrowBuf dec_cache, dec_tokens, dec_masks, dec_logits, dec_state;
+  int* dec_done_host = nullptr;  // pinned: completion counter read back while the loop runs
+  bool enc_state_valid = false;  // encoder output / cross-K/V of the last wca_greedy_decode may be re-used by the next enqueue
   // results ring: up to 2 wca_align_batch_enqueue calls may be in flight before their _fetch
   int* res_host[2] = {nullptr, nullptr};  // pinned results staging
   size_t res_host_ints[2] = {0, 0};
@@ -535,6 +539,78 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   return WCA_OK;
 }
 
+// One autoregressive step of the greedy ASR pre-pass for B rows: position t of every row (token tokens[b][t]) through
+// the decoder with the self-attention K/V cache (positions 0..t), cross-attention over this batch's cross-K/V; logits
+// of that position -> e->dec_logits. Same kernels as run_decoder with one query row per utterance.
+int run_decode_step(wca_engine* e, hipStream_t s, const half_t* kvbuf, const int* tokens, int B, int t, int T_max, bool want_logits) {
+  const wca_model_dims& D = e->dims;
+  const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
+  const float scale = 1.0f / std::sqrt((float)(dt / H));
+  half_t* cache = (half_t*)e->dec_cache.p;
+  const size_t plane = (size_t)B * T_max * dt;  // one layer's K (or V) cache
+  HIPCHK(launch_embed_step(tokens, T_max, t, e->tok_emb, e->dec_pos, e->xd, B, dt, s));
+  for (int li = 0; li < L; ++li) {
+    const LayerW& l = e->dec[li];
+    half_t* kc = cache + (size_t)(2 * li) * plane;
+    half_t* vc = kc + plane;
+    HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, B, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, B, 3 * dt, dt, 0, 0, 2));
+    HIPCHK(launch_kv_append(e->qkv_d, kc, vc, B, T_max, t, dt, s));
+    {
+      AttnArgs a{};
+      a.Q = e->qkv_d;
+      a.q_bs = 3 * dt;
+      a.q_rs = 3 * dt;
+      a.K = kc;
+      a.V = vc;
+      a.k_bs = a.v_bs = (long)T_max * dt;
+      a.k_rs = a.v_rs = dt;
+      a.O = e->att_d;
+      a.o_bs = dt;
+      a.o_rs = dt;
+      a.nq = 1;
+      a.nk = t + 1;  // the cache holds exactly the causal prefix
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 0;
+      HIPCHK(launch_attention(a, s));
+    }
+    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, B, dt, dt, 0, 2, 2));
+    HIPCHK(launch_layernorm_f16(e->xd, l.lnc_g, l.lnc_b, e->xdn, B, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, B, dt, dt, 0, 0, 2));
+    {
+      AttnArgs a{};
+      a.Q = e->q_d;
+      a.q_bs = dt;
+      a.q_rs = dt;
+      a.K = kvbuf + (size_t)(2 * li) * dt;
+      a.V = kvbuf + (size_t)(2 * li + 1) * dt;
+      a.k_bs = a.v_bs = (long)N_CTX * L * 2 * dt;
+      a.k_rs = a.v_rs = L * 2 * dt;
+      a.O = e->att_d;
+      a.o_bs = dt;
+      a.o_rs = dt;
+      a.nq = 1;
+      a.nk = N_CTX;
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 0;
+      HIPCHK(launch_attention(a, s));
+    }
+    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, B, dt, dt, 0, 2, 2));
+    HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, B, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, B, 4 * dt, dt, 1, 0, 2));
+    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, B, dt, 4 * dt, 0, 2, 2));
+  }
+  if (want_logits) {
+    HIPCHK(launch_layernorm_f16(e->xd, e->lnf_g, e->lnf_b, e->xdn, B, dt, 1e-5f, s));
+    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, e->dec_logits.p, D.n_vocab, B, D.n_vocab, dt, 0, 1, 3));
+  }
+  return WCA_OK;
+}
+
 int check_ready(wca_engine* e) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   if (!e->finalized) return fail(WCA_ERR_STATE, "weights not finalized (call wca_finalize_weights)");
@@ -766,6 +842,12 @@ void wca_engine_destroy(wca_engine* e) {
   if (e->wslab) (void)hipFree(e->wslab);
   if (e->aslab) (void)hipFree(e->aslab);
   if (e->meta_host) (void)hipHostFree(e->meta_host);
+  if (e->dec_done_host) (void)hipHostFree(e->dec_done_host);
+  e->dec_cache.release();
+  e->dec_tokens.release();
+  e->dec_masks.release();
+  e->dec_logits.release();
+  e->dec_state.release();
   for (int i = 0; i < 2; ++i) {
     if (e->res_host[i]) (void)hipHostFree(e->res_host[i]);
     if (e->res_ev[i]) (void)hipEventDestroy(e->res_ev[i]);
@@ -1309,7 +1391,11 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
                             int batch, const wca_align_opts* o) {
   int rc = check_ready(e);
   if (rc) return rc;
-  if (!pcm_dev || !n_samples_host || !tokens_dev || !n_tok_host || !max_frames_host || !o) return fail(WCA_ERR_INVALID, "null argument");
+  if (!tokens_dev || !n_tok_host || !max_frames_host || !o) return fail(WCA_ERR_INVALID, "null argument");
+  const bool reuse_enc = (pcm_dev == nullptr);  // cross-K/V of this batch already sits in the K/V buffer (wca_greedy_decode)
+  if (reuse_enc && (!e->enc_state_valid || e->last_batch != batch))
+    return fail(WCA_ERR_STATE, "pcm_dev == NULL re-uses the encoder state of the preceding wca_greedy_decode of the same batch; there is none");
+  if (!reuse_enc && !n_samples_host) return fail(WCA_ERR_INVALID, "null argument");
   if (e->enq_count - e->fetch_count >= 2) return fail(WCA_ERR_STATE, "two batches already in flight: call wca_align_batch_fetch first");
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
@@ -1318,9 +1404,10 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int Fmax = 0;
   rc = validate_lengths(batch, n_tok_max, n_tok_host, max_frames_host, &Fmax);
   if (rc) return rc;
-  for (int b = 0; b < batch; ++b)
-    if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
-      return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
+  if (!reuse_enc)
+    for (int b = 0; b < batch; ++b)
+      if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
+        return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
   const wca_model_dims& D = e->dims;
   const int LH = D.n_text_layer * D.n_text_head;
   const int Fpad = (Fmax + 3) & ~3;
@@ -1330,7 +1417,7 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     if (dn[b] < 0) dn[b] = 0;
   }
   int* rows[4];
-  rc = stage_meta(e, batch, n_samples_host, n_tok_host, max_frames_host, dn.data(), rows);
+  rc = stage_meta(e, batch, reuse_enc ? nullptr : n_samples_host, n_tok_host, max_frames_host, dn.data(), rows);
   if (rc) return rc;
   // ---- phase 1 on `stream`: log-mel, encoder, cross-K/V of all decoder layers into this batch's K/V buffer.
   // (The buffer was last read by the batch two enqueues ago, which has been fetched: at most 2 are in flight.)
@@ -1338,15 +1425,22 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   half_t* kvbuf = bs ? e->kv_alt : e->kv;
   hipStream_t s2 = e->stream2;
   record(e, 0);
-  rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
-  if (rc) return rc;
+  if (!reuse_enc) {
+    rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
+    if (rc) return rc;
+  }
   record(e, 1);
-  rc = run_encoder(e, batch);
-  if (rc) return rc;
+  if (!reuse_enc) {
+    rc = run_encoder(e, batch);
+    if (rc) return rc;
+  }
   record(e, 2);
-  rc = run_cross_kv(e, batch, kvbuf);
-  if (rc) return rc;
+  if (!reuse_enc) {
+    rc = run_cross_kv(e, batch, kvbuf);
+    if (rc) return rc;
+  }
   record(e, 3);
+  e->enc_state_valid = false;
   HIPCHK(hipEventRecord(e->ev_kv[bs], e->stream));
   // ---- phase 2 on `stream2`: decoder with capture, head statistics, top-k, aggregation, DTW, D2H. These are
   // latency-bound kernels with few workgroups; on their own stream they overlap the NEXT batch's phase 1.
@@ -1407,6 +1501,127 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   e->res_topk[rs] = k;
   e->last_batch = batch;
   e->enq_count++;
+  return WCA_OK;
+}
+
+int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
+                      int batch, const int32_t* initial_tokens_host, int n_initial, const uint8_t* suppress_mask_host,
+                      const uint8_t* blank_mask_host, const wca_decode_opts* o, int32_t* tokens_out_host, int32_t* n_tokens_host,
+                      float* sum_logprob_host) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if ((mel_dev == nullptr) == (pcm_dev == nullptr)) return fail(WCA_ERR_INVALID, "pass exactly one of mel_dev / pcm_dev");
+  if (!initial_tokens_host || !suppress_mask_host || !o || !tokens_out_host || !n_tokens_host) return fail(WCA_ERR_INVALID, "null argument");
+  if (pcm_dev && !n_samples_host) return fail(WCA_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  const wca_model_dims& D = e->dims;
+  if (n_initial < 1 || o->sample_len < 1 || n_initial + o->sample_len > D.n_text_ctx)
+    return fail(WCA_ERR_TOO_LONG, "n_initial %d + sample_len %d exceeds n_text_ctx %d", n_initial, o->sample_len, D.n_text_ctx);
+  if (o->eot < 0 || o->eot >= D.n_vocab || o->timestamp_begin < 0 || o->timestamp_begin > D.n_vocab)
+    return fail(WCA_ERR_INVALID, "eot / timestamp_begin outside the vocabulary");
+  for (int i = 0; i < n_initial; ++i)
+    if (initial_tokens_host[i] < 0 || initial_tokens_host[i] >= D.n_vocab) return fail(WCA_ERR_INVALID, "initial token %d outside the vocabulary", i);
+  if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the pending wca_align_batch_enqueue results first");
+  if (pcm_dev)
+    for (int b = 0; b < batch; ++b)
+      if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
+        return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
+  const int V = D.n_vocab, dt = D.n_text_state, L = D.n_text_layer;
+  const int T_max = n_initial + o->sample_len;
+  // ---- phase 1 on `stream` into the K/V buffer the next wca_align_batch_enqueue will use (it may re-use it: pcm_dev = NULL)
+  const int bs = (int)(e->enq_count & 1);
+  half_t* kvbuf = bs ? e->kv_alt : e->kv;
+  if (pcm_dev) {
+    int* rows[4];
+    rc = stage_meta(e, batch, n_samples_host, nullptr, nullptr, nullptr, rows);
+    if (rc) return rc;
+    rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
+    if (rc) return rc;
+  } else {
+    const size_t nel = (size_t)D.n_mels * N_FRAMES;
+    dim3 grid((unsigned)((nel + 255) / 256), batch);
+    hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
+    HIPCHK(hipGetLastError());
+  }
+  rc = run_encoder(e, batch);
+  if (rc) return rc;
+  rc = run_cross_kv(e, batch, kvbuf);
+  if (rc) return rc;
+  HIPCHK(hipEventRecord(e->ev_kv[bs], e->stream));
+  // ---- the autoregressive loop on `stream2` (it shares the decoder scratch with phase 2 of the alignment)
+  hipStream_t s2 = e->stream2;
+  HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
+  HIPCHK(e->dec_cache.ensure(sizeof(half_t) * (size_t)L * 2 * batch * T_max * dt));
+  HIPCHK(e->dec_tokens.ensure(sizeof(int) * (size_t)batch * T_max));
+  HIPCHK(e->dec_masks.ensure((size_t)2 * V));
+  HIPCHK(e->dec_logits.ensure(sizeof(float) * (size_t)batch * V));
+  HIPCHK(e->dec_state.ensure(sizeof(float) * batch + sizeof(int) * (size_t)T_max));
+  if (!e->dec_done_host) HIPCHK(hipHostMalloc((void**)&e->dec_done_host, sizeof(int) * 4, hipHostMallocDefault));
+  std::vector<int32_t> init((size_t)batch * T_max, o->eot);
+  for (int b = 0; b < batch; ++b)
+    for (int i = 0; i < n_initial; ++i) init[(size_t)b * T_max + i] = initial_tokens_host[i];
+  int* tokens_dev = (int*)e->dec_tokens.p;
+  unsigned char* masks = (unsigned char*)e->dec_masks.p;
+  float* sum_lp = (float*)e->dec_state.p;
+  int* n_done = (int*)((char*)e->dec_state.p + sizeof(float) * batch);
+  HIPCHK(hipMemcpyAsync(tokens_dev, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, s2));
+  HIPCHK(hipMemcpyAsync(masks, suppress_mask_host, V, hipMemcpyHostToDevice, s2));
+  if (blank_mask_host) HIPCHK(hipMemcpyAsync(masks + V, blank_mask_host, V, hipMemcpyHostToDevice, s2));
+  HIPCHK(hipMemsetAsync(e->dec_state.p, 0, sizeof(float) * batch + sizeof(int) * (size_t)T_max, s2));
+  HIPCHK(hipStreamSynchronize(s2));  // `init` is pageable host memory
+  DecodeSelectArgs sel{};
+  sel.logits = (const float*)e->dec_logits.p;
+  sel.ld = V;
+  sel.n_vocab = V;
+  sel.tokens = tokens_dev;
+  sel.T_max = T_max;
+  sel.n_initial = n_initial;
+  sel.suppress_mask = masks;
+  sel.blank_mask = blank_mask_host ? masks + V : nullptr;
+  sel.eot = o->eot;
+  sel.timestamp_begin = o->timestamp_begin;
+  sel.apply_timestamp_rules = o->apply_timestamp_rules;
+  sel.max_initial_timestamp_index = o->max_initial_timestamp_index;
+  sel.sum_logprob = sum_lp;
+  sel.n_done = n_done;
+  // the prompt is fed one position at a time (it is 3 tokens: sot, language, task); sampling starts after its last token
+  int steps = 0;
+  for (int t = 0; t < T_max - 1; ++t) {
+    const bool sample = (t >= n_initial - 1);
+    rc = run_decode_step(e, s2, kvbuf, tokens_dev, batch, t, T_max, sample);
+    if (rc) return rc;
+    if (!sample) continue;
+    sel.cur_len = t + 1;
+    HIPCHK(launch_decode_select(sel, batch, s2));
+    ++steps;
+    // whisper's loop ends when every row has produced EOT (checked every 4 steps here: a late stop only costs time,
+    // finished rows keep emitting EOT) or after sample_len steps
+    if ((steps & 3) == 0 || steps == o->sample_len) {
+      HIPCHK(hipMemcpyAsync(e->dec_done_host, n_done + t + 1, sizeof(int), hipMemcpyDeviceToHost, s2));
+      HIPCHK(hipStreamSynchronize(s2));
+      if (e->dec_done_host[0] >= batch) break;
+    }
+    if (steps >= o->sample_len) break;
+  }
+  std::vector<int32_t> toks((size_t)batch * T_max);
+  HIPCHK(hipMemcpyAsync(toks.data(), tokens_dev, sizeof(int) * toks.size(), hipMemcpyDeviceToHost, s2));
+  std::vector<float> lp(batch);
+  HIPCHK(hipMemcpyAsync(lp.data(), sum_lp, sizeof(float) * batch, hipMemcpyDeviceToHost, s2));
+  HIPCHK(hipStreamSynchronize(s2));
+  const int n_have = n_initial + steps;  // positions written so far
+  for (int b = 0; b < batch; ++b) {
+    int n = n_have;
+    for (int i = n_initial; i < n_have; ++i)
+      if (toks[(size_t)b * T_max + i] == o->eot) {
+        n = i;
+        break;
+      }
+    n_tokens_host[b] = n;  // tokens_out[b][n_initial : n] are the sampled tokens before the first EOT
+    for (int i = 0; i < T_max; ++i) tokens_out_host[(size_t)b * T_max + i] = (i < n_have) ? toks[(size_t)b * T_max + i] : o->eot;
+    if (sum_logprob_host) sum_logprob_host[b] = lp[b];
+  }
+  e->enc_state_valid = true;
+  e->last_batch = batch;
   return WCA_OK;
 }
 
@@ -1521,6 +1736,31 @@ int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, cons
                                unsigned long long* dbg_dev) {
   if (!dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
   return test_attention_impl(e, q, k, v, o, nullptr, 0, 0, B, H, nq, nk, 0, dbg_dev);
+}
+
+int wca_test_decode_select(wca_engine* e, const float* logits_dev, int batch, int n_vocab, int32_t* tokens_dev, int T_max, int cur_len,
+                           int n_initial, const uint8_t* suppress_mask_dev, const uint8_t* blank_mask_dev, const wca_decode_opts* o,
+                           float* sum_logprob_dev, int32_t* n_done_dev) {
+  if (!e || !logits_dev || !tokens_dev || !suppress_mask_dev || !o || !sum_logprob_dev || !n_done_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  DecodeSelectArgs a{};
+  a.logits = logits_dev;
+  a.ld = n_vocab;
+  a.n_vocab = n_vocab;
+  a.tokens = tokens_dev;
+  a.T_max = T_max;
+  a.cur_len = cur_len;
+  a.n_initial = n_initial;
+  a.suppress_mask = suppress_mask_dev;
+  a.blank_mask = blank_mask_dev;
+  a.eot = o->eot;
+  a.timestamp_begin = o->timestamp_begin;
+  a.apply_timestamp_rules = o->apply_timestamp_rules;
+  a.max_initial_timestamp_index = o->max_initial_timestamp_index;
+  a.sum_logprob = sum_logprob_dev;
+  a.n_done = n_done_dev;
+  HIPCHK(launch_decode_select(a, batch, e->stream));
+  return WCA_OK;
 }
 
 int wca_test_layernorm(wca_engine* e, const float* x, const float* g, const float* b, void* out, int rows, int d) {

@@ -61,6 +61,28 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x,
                         int B, int n, int d, hipStream_t s);
 hipError_t launch_fill_f16(half_t* p, size_t n, float v, hipStream_t s);
+
+// ---------------------------------------------------------------- greedy ASR decode steps (decode.hip)
+// x[b][:] = tok_emb[tokens[b*T_max + t]][:] + pos_emb[t][:]
+hipError_t launch_embed_step(const int* tokens, int T_max, int t, const half_t* tok_emb, const float* pos_emb, float* x, int B, int d,
+                             hipStream_t s);
+// k / v columns of qkv [B][3d] -> kc / vc [B][T_max][d] at position t
+hipError_t launch_kv_append(const half_t* qkv, half_t* kc, half_t* vc, int B, int T_max, int t, int d, hipStream_t s);
+// logit filters + greedy update of one decoding step (upstream decoding.py: SuppressBlank, SuppressTokens,
+// ApplyTimestampRules, GreedyDecoder.update at temperature 0); one workgroup per batch row
+struct DecodeSelectArgs {
+  const float* logits;                 // [B] rows, ld apart: the last position's fp32 logits
+  int ld, n_vocab;
+  int* tokens;                         // [B][T_max]; row b holds cur_len tokens, the new one is written at [cur_len]
+  int T_max, cur_len, n_initial;
+  const unsigned char* suppress_mask;  // [n_vocab] 1 = always -inf (SuppressTokens, <|notimestamps|>)
+  const unsigned char* blank_mask;     // [n_vocab] 1 = -inf on the first sampled position (SuppressBlank); nullable
+  int eot, timestamp_begin;
+  int apply_timestamp_rules, max_initial_timestamp_index;  // index < 0: no limit
+  float* sum_logprob;                  // [B] accumulated log-probability of the sampled tokens
+  int* n_done;                         // [T_max] n_done[cur_len] += 1 for every row whose new token is EOT
+};
+hipError_t launch_decode_select(const DecodeSelectArgs& a, int B, hipStream_t s);
 hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- log-mel (logmel.hip)

@@ -234,12 +234,47 @@ class WhisperAMD:
         """Fused pipeline. pcm [B,stride] f32 cuda, tokens [B,n_max] int64 cuda. Returns (jump_frames [B,n_max] int32, sel [B,topk])."""
         B, n_max = tokens.shape
         self._bind_stream()
-        args = (self._h, _ptr(pcm), pcm.shape[1], _lib.i32_array(n_samples), _ptr(tokens), n_max, _lib.i32_array(n_tok),
+        # pcm=None re-uses the encoder state left by the preceding greedy_decode of the same batch
+        args = (self._h, _ptr(pcm) if pcm is not None else None, pcm.shape[1] if pcm is not None else 0,
+                _lib.i32_array(n_samples) if n_samples is not None else None, _ptr(tokens), n_max, _lib.i32_array(n_tok),
                 _lib.i32_array(max_frames), B, C.byref(opts))
         _lib.check(self._lib.wca_align_batch_enqueue(*args))
         if enqueue_only:
             return None
         return self.fetch(B, n_max, opts)
+
+    def greedy_decode(self, mel, pcm, n_samples, initial_tokens, suppress_mask, blank_mask, sample_len, eot, timestamp_begin,
+                      apply_timestamp_rules=True, max_initial_timestamp_index=50):
+        """C ABI wca_greedy_decode. mel [B,n_mels,3000] f32 cuda XOR pcm [B,stride] f32 cuda (+ n_samples).
+        Returns (tokens [B, n_initial+sample_len] int32, n_tokens [B] int32, sum_logprobs [B] f32) as numpy arrays; the
+        encoder state stays in the engine for a following align_batch(pcm=None, ...)."""
+        self._bind_stream()
+        B = mel.shape[0] if mel is not None else pcm.shape[0]
+        n_init = len(initial_tokens)
+        T = n_init + int(sample_len)
+        tokens = np.zeros((B, T), dtype=np.int32)
+        n_tok = np.zeros(B, dtype=np.int32)
+        lp = np.zeros(B, dtype=np.float32)
+        sup = np.ascontiguousarray(suppress_mask, dtype=np.uint8)
+        blank = np.ascontiguousarray(blank_mask, dtype=np.uint8) if blank_mask is not None else None
+        if sup.shape[0] != self.dims.n_vocab or (blank is not None and blank.shape[0] != self.dims.n_vocab):
+            raise ValueError("filter masks must have n_vocab entries")
+        opts = _lib.DecodeOpts(int(sample_len), int(eot), int(timestamp_begin), 1 if apply_timestamp_rules else 0,
+                               int(max_initial_timestamp_index))
+        if mel is not None:
+            mel = mel.contiguous().float()
+        _lib.check(self._lib.wca_greedy_decode(
+            self._h, _ptr(mel) if mel is not None else None, _ptr(pcm) if pcm is not None else None,
+            pcm.shape[1] if pcm is not None else 0, _lib.i32_array(n_samples) if n_samples is not None else None, B,
+            _lib.i32_array(initial_tokens), n_init, sup.ctypes.data_as(C.c_void_p),
+            blank.ctypes.data_as(C.c_void_p) if blank is not None else None, C.byref(opts),
+            tokens.ctypes.data_as(_lib._pi32), n_tok.ctypes.data_as(_lib._pi32), lp.ctypes.data_as(_lib._pf)))
+        return tokens, n_tok, lp
+
+    def decode(self, mel, options=None):
+        """whisper.decode(model, mel, options) (infer_ali.py:60)."""
+        from . import decoding
+        return decoding.decode(self, mel, options if options is not None else decoding.DecodingOptions())
 
     def fetch(self, B, n_max, opts):
         k = opts.topk if opts.aggregation == _lib.AGGR_TOPK else 0

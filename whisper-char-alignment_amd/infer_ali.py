@@ -10,8 +10,9 @@ MI355X engine. Same flags, same result JSON ({args..., precision, recall, f1, r_
 Additions: --weights (LOCAL openai-format checkpoint; nothing is fetched by name), --random_init,
 --batch_size (utterances per micro-batch through the fused wca_align_batch path), --vocab (local
 tiktoken file, needed for --aligned_unit_type subword), --teacher.
-The reference teacher-forces the ASR hypothesis of whisper.decode (infer_ali.py:60-68); the greedy decode
-pre-pass is not part of this engine yet, so the teacher text is the dataset transcript (--teacher text).
+--teacher asr runs the reference's flow (greedy whisper.decode pre-pass, infer_ali.py:60-68, then teacher-forcing of its
+hypothesis; the encoder runs ONCE per utterance, the reference runs it twice); --teacher text (default) teacher-forces
+the dataset transcript and skips the pre-pass.
 Utterances with max_frames > 1500 or more than 448 tokens are skipped and their id printed
 (infer_ali.py:78-81).
 """
@@ -40,6 +41,7 @@ from .retokenize import encode, remove_punctuation  # noqa: E402
 from .timing import words_from_jump_frames, default_find_alignment  # noqa: E402
 from .audio import log_mel_spectrogram, pad_or_trim  # noqa: E402
 from .tokenizer import get_tokenizer  # noqa: E402
+from .decoding import DecodingOptions, decode  # noqa: E402
 
 DATASET = {"TIMIT": TIMIT, "LibriSpeech": LibriSpeech}
 
@@ -71,8 +73,10 @@ def infer_dataset(args):
     if args.n_mels != model.dims.n_mels:
         raise SystemExit("--n_mels %d does not match the checkpoint (%d); large-v3 needs --n_mels 128" % (args.n_mels, model.dims.n_mels))
     tokenizer = get_tokenizer(model.is_multilingual, language="English", vocab_path=args.vocab)
-    if args.teacher != "text":
-        raise SystemExit("--teacher asr needs the greedy decode pre-pass, which is not implemented in this engine yet")
+    # language="en" + task=transcribe -> ASR and alignment using whisper (infer_ali.py:40)
+    asr_options = DecodingOptions(language="en", vocab_path=args.vocab)
+    if args.teacher == "asr" and args.vocab is None and not args.random_init:
+        raise SystemExit("--teacher asr turns token ids back into text: pass --vocab <local multilingual.tiktoken>")
     dataset = DATASET[args.dataset](args.scp, n_mels=args.n_mels, device=device, model=model, compute_mel=False)
     mine = _shard.shard_indices(len(dataset), rank, world, [dataset.duration_hint(i) for i in range(len(dataset))])
     opts = model.make_opts(aggregation=args.aggr, topk=args.topk, w_colnorm=args.w_colnorm, w_rownorm=args.w_rownorm,
@@ -87,15 +91,39 @@ def infer_dataset(args):
         if not batch:
             return
         smax = max(len(b["pcm"]) for b in batch)
-        n_max = max(len(b["tokens"]) for b in batch)
         pcm = np.zeros((len(batch), smax), dtype=np.float32)
-        toks = np.full((len(batch), n_max), tokenizer.eot, dtype=np.int64)
         for j, b in enumerate(batch):
             pcm[j, :len(b["pcm"])] = b["pcm"]
+        pcm_dev = torch.from_numpy(pcm).to(device)
+        n_samples = [len(b["pcm"]) for b in batch]
+        reuse = False
+        if args.teacher == "asr":
+            # greedy ASR pre-pass (infer_ali.py:60-61); its encoder output is re-used by the alignment below
+            results = decode(model, None, asr_options, pcm=pcm_dev, n_samples=n_samples)
+            reuse = True
+            for b, r in zip(batch, results):
+                transcription = remove_punctuation(r.text)  # infer_ali.py:64
+                try:
+                    b["text_tokens"] = encode(transcription, tokenizer, args.aligned_unit_type)
+                except Exception as exc:  # non-ASCII hypothesis without a vocabulary file
+                    print("%s: cannot tokenize the ASR hypothesis (%s)" % (b["fid"], exc))
+                    b["text_tokens"] = None
+                if b["text_tokens"] is not None:
+                    b["tokens"] = [*tokenizer.sot_sequence, tokenizer.no_timestamps, *b["text_tokens"], tokenizer.eot]
+                if b["text_tokens"] is None or len(b["tokens"]) > MAX_LENGTH:
+                    print(b["fid"])  # infer_ali.py:79-81; the row stays in the batch (its encoder state is in place) but is not scored
+                    b["skip"] = True
+                    b["text_tokens"] = []
+                    b["tokens"] = [*tokenizer.sot_sequence, tokenizer.no_timestamps, tokenizer.eot]
+        n_max = max(len(b["tokens"]) for b in batch)
+        toks = np.full((len(batch), n_max), tokenizer.eot, dtype=np.int64)
+        for j, b in enumerate(batch):
             toks[j, :len(b["tokens"])] = b["tokens"]
-        jump, _ = model.align_batch(torch.from_numpy(pcm).to(device), [len(b["pcm"]) for b in batch], torch.from_numpy(toks).to(device),
+        jump, _ = model.align_batch(None if reuse else pcm_dev, None if reuse else n_samples, torch.from_numpy(toks).to(device),
                                     [len(b["tokens"]) for b in batch], [b["max_frames"] for b in batch], opts)
         for j, b in enumerate(batch):
+            if b.get("skip"):
+                continue
             words, start_times, end_times = words_from_jump_frames(jump[j], b["text_tokens"], tokenizer, args.aligned_unit_type)
             ends_hat = end_times
             local_times[b["index"]] = (start_times, end_times)
@@ -119,15 +147,24 @@ def infer_dataset(args):
     for n in mine:
         audio, _mel, duration, texts, starts, ends, fid = dataset[n]
         texts = remove_punctuation(texts)
-        transcription = texts  # --teacher text
-        text_tokens = encode(transcription, tokenizer, args.aligned_unit_type)
-        tokens = [*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]
         max_frames = duration // AUDIO_SAMPLES_PER_TOKEN
+        if args.teacher == "text":
+            transcription = texts  # the dataset transcript is teacher-forced
+            text_tokens = encode(transcription, tokenizer, args.aligned_unit_type)
+            tokens = [*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]
+        else:
+            text_tokens, tokens = None, []  # filled from the ASR hypothesis when the micro-batch is flushed
         if max_frames > MAX_FRAMES or len(tokens) > MAX_LENGTH or max_frames < 1:
             print(fid)
             continue
         if args.default_whisper_timing:  # per-utterance path (timing.py:116-186), not the fused batch path
             mel = log_mel_spectrogram(pad_or_trim(audio), args.n_mels, model=model)
+            if args.teacher == "asr":
+                transcription = remove_punctuation(decode(model, mel, asr_options).text)
+                text_tokens = encode(transcription, tokenizer, args.aligned_unit_type)
+                if len(text_tokens) + len(tokenizer.sot_sequence) + 2 > MAX_LENGTH:
+                    print(fid)
+                    continue
             words, start_times, end_times, _ws, _ = default_find_alignment(model, tokenizer, text_tokens, mel, int(max_frames),
                                                                          medfilt_width=args.medfilt_width)
             local_times[n] = (np.asarray(start_times, dtype=np.float64), np.asarray(end_times, dtype=np.float64))
@@ -188,7 +225,8 @@ def parse_args(argv=None):
     p.add_argument("--random_init", action="store_true", help="seeded random weights (dry run without a checkpoint)")
     p.add_argument("--vocab", type=str, default=None, help="local tiktoken vocabulary file (subword mode / non-ASCII text)")
     p.add_argument("--batch_size", type=int, default=16, help="utterances per micro-batch on each GPU")
-    p.add_argument("--teacher", type=str, default="text", choices=["text", "asr"])
+    p.add_argument("--teacher", type=str, default="text", choices=["text", "asr"],
+                   help="asr: greedy decode pre-pass gives the teacher text (the reference's behaviour); text: dataset transcript")
     return p.parse_args(argv)
 
 

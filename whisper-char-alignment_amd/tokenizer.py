@@ -100,6 +100,43 @@ class Tokenizer:
         return self.special_tokens["<|0.00|>"]
 
     @cached_property
+    def sot_lm(self):
+        return self.special_tokens["<|startoflm|>"]
+
+    @cached_property
+    def sot_prev(self):
+        return self.special_tokens["<|startofprev|>"]
+
+    @cached_property
+    def no_speech(self):
+        return self.special_tokens["<|nospeech|>"]
+
+    @cached_property
+    def non_speech_tokens(self):
+        """whisper.tokenizer.Tokenizer.non_speech_tokens (upstream, restated): tokens of speaker tags / non-speech
+        annotations that SuppressTokens removes. A symbol contributes when it (or " " + it) encodes to ONE token, the
+        musical symbols always contribute their first token. Without a vocabulary file only single-byte symbols can
+        be encoded, so the list then holds just those (enough for the byte-level dry-run vocabulary)."""
+        symbols = list('"#()*+/:;<=>@[\\]^_`{|}~「」『』')
+        symbols += "<< >> <<< >>> -- --- -( -[ (' (\" (( )) ((( ))) [[ ]] {{ }} ♪♪ ♫♫".split()
+        miscellaneous = set("♩♪♫♬♭♮♯")
+        result = set()
+        for first in (" -", " '"):
+            try:
+                result.add(self.encode(first)[0])
+            except NeedVocabError:
+                pass
+        for symbol in symbols + list(miscellaneous):
+            for text in (symbol, " " + symbol):
+                try:
+                    tokens = self.encode(text)
+                except NeedVocabError:
+                    continue
+                if len(tokens) == 1 or symbol in miscellaneous:
+                    result.add(tokens[0])
+        return tuple(sorted(result))
+
+    @cached_property
     def sot_sequence(self):
         seq = [self.sot]
         if self.language is not None:
@@ -107,6 +144,10 @@ class Tokenizer:
         if self.task is not None:
             seq.append(self.transcribe if self.task == "transcribe" else self.translate)
         return tuple(seq)
+
+    @cached_property
+    def sot_sequence_including_notimestamps(self):
+        return tuple(list(self.sot_sequence) + [self.no_timestamps])
 
     # ---- encode / decode
     def _bpe(self, piece):
@@ -144,6 +185,8 @@ class Tokenizer:
             return self._bytes_of[t]
         if t in self._special_text:
             return self._special_text[t].encode()
+        if not self.has_vocab:
+            raise NeedVocabError("token id %d cannot be decoded without the BPE vocabulary: pass vocab_path=<local *.tiktoken file>" % t)
         raise KeyError("token id %d is neither in the loaded vocabulary nor a special token" % t)
 
     def decode(self, tokens):
