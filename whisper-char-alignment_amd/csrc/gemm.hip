@@ -436,7 +436,22 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   //     (64-byte DMA segments on operands that miss L2), bench unchanged.)
   int v = blockIdx.x;
   int id = xcd_remap(v, nwg);
-  int m0 = (id / ntn) * 256, n0 = (id % ntn) * 256;
+  // logical id -> tile: supertiles of SM m-panels swept n-major, m fastest inside. The 32 workgroups that share an
+  // XCD's L2 hold 32 consecutive ids = SM m-panels x 32/SM n-panels, and the following rounds walk the same SM
+  // activation panels across the remaining n-panels, so those are re-read from L2 instead of the fabric. SM is
+  // chosen in launch_gemm (measured, M = 48000: fc1 870 -> 921-960 TFLOP/s at SM 8-16, QKV +2-3 %; K = 4096 and
+  // N = 49152 lose 2-10 % with SM > 1 and keep the row-major order).
+  const int SM = a.supertile > 0 ? a.supertile : 1;
+  auto tile_of = [&](int t, int& tm, int& tn) {
+    const int per = SM * ntn;
+    const int st = t / per, r = t - st * per;
+    const int rows = (ntm - st * SM) < SM ? (ntm - st * SM) : SM;  // the last supertile may be short
+    tn = r / rows;
+    tm = st * SM + (r - tn * rows);
+  };
+  int tm_, tn_;
+  tile_of(id, tm_, tn_);
+  int m0 = tm_ * 256, n0 = tn_ * 256;
   unsigned ta = (unsigned)m0 * a.lda * 2u, tw = (unsigned)n0 * a.ldw * 2u;
 
   f32x4 acc[8][4];
@@ -475,7 +490,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     const int vn = v + G;
     const bool has_next = vn < nwg;
     const int idn = has_next ? xcd_remap(vn, nwg) : id;
-    const int m0n = (idn / ntn) * 256, n0n = (idn % ntn) * 256;
+    int tmn_, tnn_;
+    tile_of(idn, tmn_, tnn_);
+    const int m0n = tmn_ * 256, n0n = tnn_ * 256;
     const unsigned tan = (unsigned)m0n * a.lda * 2u, twn = (unsigned)n0n * a.ldw * 2u;
     for (int kt = 0; kt < nk; ++kt) {
       const int cur = kt & 1;
@@ -613,6 +630,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       // over a tile boundary only for an even number of K tiles); force_tile 258 = one tile per workgroup
       const int nk = a.K / BK;
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
+      if (a.supertile <= 0) a.supertile = (a.K <= 1024 && (a.N + 255) / 256 <= 32) ? 8 : 1;
     }
   } else {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;

@@ -31,7 +31,8 @@ struct GemmArgs {
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
-  int site;                // 0 generic, 1 encoder block, 2 decoder, 3 conv stem / cross-KV / logits: selects a distinct
+  int site;
+  int supertile;  // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)                // 0 generic, 1 encoder block, 2 decoder, 3 conv stem / cross-KV / logits: selects a distinct
                            // kernel symbol per call site so rocprofv3 --stats separates the shapes
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
