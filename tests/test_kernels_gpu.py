@@ -59,6 +59,38 @@ def test_gemm(eng, lib, wca, M, N, K, mode, tile):
 
 
 @pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 1024), (37, 3072, 1024), (64, 1000, 4096), (1, 4096, 512), (3, 51865, 1024)])
+def test_gemm_skinny(eng, lib, wca, M, N, K, mode):
+    """M <= 64 weight-streaming kernel of the greedy-decode steps (ragged M, N not a multiple of 16, the logits shape)
+    against an fp32 matmul of the same f16 operands; tolerances as in test_gemm."""
+    g = torch.Generator().manual_seed(M * 11 + N + K)
+    ad = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
+    wd = (torch.randn(N, K, generator=g) * 0.1).half().cuda()
+    bd = torch.randn(N, generator=g).cuda()
+    ref = ad.float() @ wd.float().T + bd
+    tile = 64
+    if mode in ("f16", "f16_gelu"):
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        gelu = int(mode == "f16_gelu")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0 | (tile << 8)))
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
+    elif mode == "f32":
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 1 | (tile << 8)))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-4)
+    else:
+        base = torch.randn(M, N, generator=g).cuda()
+        out = base.clone()
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2 | (tile << 8)))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, base + ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
 @pytest.mark.parametrize("tile", [257])
 @pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024)])
 def test_gemm_persistent_many_tiles(eng, lib, wca, M, N, K, mode, tile):

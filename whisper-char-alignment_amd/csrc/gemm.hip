@@ -595,6 +595,106 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 #undef WCA_LOAD_HALF
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMM for M <= 64 rows (one greedy-decode step: M = batch): weight streaming, latency-bound. A workgroup owns
+// 16 output columns for all rows; its four waves split K into quarters, each multiplying its K range for the four
+// 16-row m-tiles with operands loaded straight from global memory into MFMA fragments (no LDS staging: every weight
+// byte is used once, the <= 64 x K activation block is L2-resident and shared by all workgroups); chunks of 128 K
+// values are double-buffered in registers so the next chunk's 20 loads are in flight under the current MFMAs. The
+// four partial accumulators are summed through LDS and each wave finishes one m-tile (bias, GELU, f16 / f32 / += f32).
+// Grid = N / 16 workgroups (192-256 for the decoder's N = 3072 / 4096, 64 for N = 1024) instead of the 8-32 of the
+// 128 x 128 tile kernel.
+template <int OUT_MODE, bool GELU>
+__global__ __launch_bounds__(256) void gemm_skinny_f16_kernel(GemmArgs a) {
+  __shared__ float red[4][4][4][64];  // [wave][m-tile][reg][lane]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int kq = a.K >> 2;            // K range of one wave (a multiple of 128, checked by launch_gemm)
+  const int kbeg = wave * kq;
+  int nrow = n0 + fr;
+  nrow = nrow < a.N ? nrow : a.N - 1;  // columns past N: duplicated weights, results not stored
+  const half_t* wp = a.W + (long)nrow * a.ldw + kbeg + fg * 8;
+  const half_t* xp[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    int m = mt * 16 + fr;
+    m = m < a.M ? m : a.M - 1;
+    xp[mt] = a.A + (long)m * a.lda + kbeg + fg * 8;
+  }
+  f32x4 acc[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  half8 wf[2][4], xf[2][4][4];
+  auto load_chunk = [&](int buf, int k) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      wf[buf][u] = *reinterpret_cast<const half8*>(wp + k + u * 32);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) xf[buf][u][mt] = *reinterpret_cast<const half8*>(xp[mt] + k + u * 32);
+    }
+  };
+  auto mul_chunk = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[buf][u], xf[buf][u][mt], acc[mt], 0, 0, 0);
+  };
+  load_chunk(0, 0);
+  for (int k = 0; k < kq; k += 256) {
+    if (k + 128 < kq) load_chunk(1, k + 128);
+    mul_chunk(0);
+    if (k + 256 < kq) load_chunk(0, k + 256);
+    if (k + 128 < kq) mul_chunk(1);
+  }
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][mt][r][lane] = acc[mt][r];
+  __syncthreads();
+  // wave w finishes m-tile w: lane holds C[m = w*16 + fr][n = n0 + 4*fg + r]
+  const int m = wave * 16 + fr;
+  float v[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = red[0][wave][r][lane] + red[1][wave][r][lane] + red[2][wave][r][lane] + red[3][wave][r][lane];
+  if (m >= a.M) return;
+  const int nb = n0 + 4 * fg;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int n = nb + r;
+    if (a.bias != nullptr && n < a.N) v[r] += a.bias[n];
+    if (GELU) v[r] = gelu_erf(v[r]);
+  }
+  long coff;
+  if (a.c_rows_per_batch > 0) {
+    const int b = m / a.c_rows_per_batch;
+    coff = (long)b * a.c_batch_stride + (long)(m - b * a.c_rows_per_batch) * a.ldc;
+  } else {
+    coff = (long)m * a.ldc;
+  }
+  if (OUT_MODE == 0) {
+    half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
+    if (nb + 4 <= a.N && (reinterpret_cast<uintptr_t>(cp) & 7) == 0) {
+      half4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+      *reinterpret_cast<half4*>(cp) = o;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nb + r < a.N) cp[r] = (half_t)v[r];
+    }
+  } else {
+    float* cp = reinterpret_cast<float*>(a.C) + coff + nb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (nb + r < a.N) cp[r] = (OUT_MODE == 2) ? cp[r] + v[r] : v[r];
+  }
+}
+
 }  // namespace
 
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
@@ -602,6 +702,23 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
   if (a.K <= 0 || (a.K % BK) != 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
+  // M <= 64 (greedy-decode steps): weight-streaming skinny kernel; force_tile 64 forces it, 128 etc. bypass it
+  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr) {
+    const dim3 sgrid((unsigned)((a.N + 15) / 16)), sblock(256);
+#define WCA_LAUNCH_SK(OM, G) hipLaunchKernelGGL((gemm_skinny_f16_kernel<OM, G>), sgrid, sblock, 0, s, a)
+    if (a.out_mode == 0) {
+      if (a.gelu) WCA_LAUNCH_SK(0, true); else WCA_LAUNCH_SK(0, false);
+    } else if (a.out_mode == 1) {
+      if (a.gelu) WCA_LAUNCH_SK(1, true); else WCA_LAUNCH_SK(1, false);
+    } else if (a.out_mode == 2 && !a.gelu) {
+      WCA_LAUNCH_SK(2, false);
+    } else {
+      return hipErrorInvalidValue;
+    }
+#undef WCA_LAUNCH_SK
+    return hipGetLastError();
+  }
+  if (a.force_tile == 64) return hipErrorInvalidValue;
   // tile choice: the 256^2 kernel runs one workgroup per CU, so it needs about a full wave of 256 workgroups
   const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const size_t a_need = ((size_t)(a.M - 1) * a.lda + a.K) * sizeof(half_t), w_need = ((size_t)(a.N - 1) * a.ldw + a.K) * sizeof(half_t);
