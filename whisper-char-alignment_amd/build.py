@@ -17,6 +17,10 @@ HEADERS = ["kernels.h", "wca_common.h", "gemm_epilogue.h", os.path.join("..", ".
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (the softmax / epilogue VALU code reads them
 # directly; the AGPR form costs a v_accvgpr_read/write pair per element in the attention loop)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+# attention.hip: no NaN can occur in the online softmax (masked scores are -inf, the -inf - -inf cases are guarded), and
+# without this flag every fmaxf on a cross-lane / MFMA result is preceded by a canonicalising v_max_f32 x, x
+# (16 of the 24 v_max per 64-key tile, in a VALU-bound loop)
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -45,7 +49,7 @@ def build_lib(force=False, verbose=True):
 
     def cc(job):
         s, o = job
-        cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))

@@ -425,7 +425,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
   //  fetch/MFMA orders or different DMA-issue windows to break SIMD-partner lockstep; a software L2 prefetch
   //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %);
-  //  padding the leading dimensions off a power of two; de-phasing the workgroups' start by up to 1/8 tile.
+  //  padding the leading dimensions off a power of two; de-phasing the workgroups' start by up to 1/8 tile;
+  //  the non-temporal hint (aux = 2) on the W stream to keep the activation panels in L2 (-7...-9 %: the workgroups
+  //  that share an n-panel then stop sharing it through L2).
   //  Two re-designs around a ring of FOUR K=32 slots (64-byte LDS rows, chunk ^ ((r>>1)&3), DMA four steps ahead,
   //  counted vmcnt, one barrier per K=32 step), both parity-green, neither faster in the pipeline:
   //   * four waves, one per SIMD, 128x128 per wave with the 256 accumulators in AGPRs (inline-asm in-place MFMA):
