@@ -224,3 +224,24 @@ def test_default_find_alignment_vs_oracle(wca, setup):
     assert np.array_equal(st, (tj[jumps] / 50)[wb[:-1]]) and np.array_equal(en, (tj[jumps] / 50)[wb[1:]])
     assert [w_.strip() for w_ in words[:-1]] == text.split()
     model.set_alignment_heads([(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)])
+
+
+def test_force_align_subword_mode(wca, fake_vocab):
+    """--aligned_unit_type subword (needs a vocabulary file): same GPU pipeline, word merge by tokenizer.split_to_word_tokens
+    (retokenize.py:22); against the CPU oracle with the same word split."""
+    syn, tk, retok, tm, audio = _mods()
+    from oracle import timing_ref
+    tok = tk.get_tokenizer(True, language="English", vocab_path=fake_vocab)
+    text = "the quick brown fox jumps"
+    tt = retok.encode(text, tok, "subword")
+    n = len(tok.sot_sequence) + 1 + len(tt) + 1
+    g = torch.Generator().manual_seed(11)
+    L, H, F = 2, 4, 180
+    w = torch.softmax(torch.randn(L, H, n, F, generator=g) * 4, -1)
+    words, st, en, matrix, scores = tm.force_align(w.cuda(), tt, tok, "subword", "topk", topk=3)
+    rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(
+        w, tt, tok, "subword", "topk", 3, split_fn=lambda tokens, tokenizer, unit: tokenizer.split_to_word_tokens(tokens))
+    assert words == rwords and "".join(words[:-1]) == text
+    assert len(st) == len(words) - 1
+    assert np.max(np.abs(np.asarray(st) - np.asarray(rst))) <= 0.02 + 1e-9
+    assert np.max(np.abs(np.asarray(en) - np.asarray(ren))) <= 0.02 + 1e-9

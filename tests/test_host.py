@@ -183,3 +183,34 @@ def test_decoding_suppress_lists_and_masks():
     ids3 = decoding.suppress_token_ids(tok, decoding.DecodingOptions(language="en", suppress_tokens=(11, 12)))
     assert 11 in ids3 and 12 in ids3 and tok.encode("(")[0] not in ids3
     assert abs(decoding.compression_ratio("aaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaaa") - 40 / len(__import__("zlib").compress(b"a" * 40))) < 1e-12
+
+
+def test_subword_tokenizer_with_vocabulary_file(fake_vocab):
+    """--aligned_unit_type subword needs the BPE table: tiktoken-format file, GPT-2 pre-tokenisation
+    pattern, rank-ordered merges; round trip and the word split (retokenize.py:22 -> tokenizer.split_to_word_tokens)."""
+    import importlib
+    tokmod = importlib.import_module("whisper-char-alignment_amd.tokenizer")
+    retok = importlib.import_module("whisper-char-alignment_amd.retokenize")
+    tok = tokmod.get_tokenizer(True, language="en", vocab_path=fake_vocab)
+    assert tok.has_vocab and tok.n_vocab == 51865
+    text = "hello world it's 42 o'clock"
+    toks = retok.encode(text, tok, "subword")
+    assert toks == tok.encode(text) and tok.decode(toks) == text
+    # a merge that exists in the table is taken: 'aa' is not there, the 4-letter token 'aaaa' cannot be built from bytes
+    assert len(tok.encode("aaaa")) == 4
+    words, word_tokens = retok.split_tokens_on_spaces(toks + [tok.eot], tok, "subword")
+    assert "".join(words) == text + "<|endoftext|>"
+    assert [t for wt in word_tokens for t in wt] == toks + [tok.eot]
+    assert words[0] == "hello" and words[1] == " world" and words[-1] == "<|endoftext|>"
+    # non-ASCII text encodes to UTF-8 byte tokens and survives the unicode-aware split
+    toks2 = tok.encode("café ñ")
+    assert tok.decode(toks2) == "café ñ"
+    pieces, piece_tokens = tok.split_tokens_on_unicode(toks2)
+    assert "".join(pieces) == "café ñ" and all("�" not in p for p in pieces)
+    # a wrong-sized vocabulary file is rejected
+    import pytest
+    bad = fake_vocab + ".bad"
+    with open(fake_vocab, "rb") as f, open(bad, "wb") as g:
+        g.write(b"".join(f.readlines()[:100]))
+    with pytest.raises(ValueError):
+        tokmod.get_tokenizer(True, language="en", vocab_path=bad)
