@@ -66,6 +66,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     qf[sub][1] = *reinterpret_cast<const half8*>(qp + 32);
   }
 
+  // LAZY (every variant without capture): the softmax runs on s' = (q * scale*log2e) . k  -  m_running, produced
+  // DIRECTLY by the S^T MFMAs: Q fragments are pre-multiplied once (f16 round of q*c; the capture variant keeps the
+  // exact fp32 scaling of the raw logits the reference's hooks see) and the accumulator starts at -m_running, so the
+  // per-element fma(s, c, -m*c) of the textbook form disappears from the VALU-bound loop (32 of ~150 VALU
+  // instructions per 64-key tile). A row whose maximum grows is fixed up in the (rare, wave-uniform) rescale branch.
+  constexpr bool LAZY = !CAPTURE;
+  const float c_log2 = a.scale * LOG2E;
+  if (LAZY) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[sub][ks][j] = (half_t)((float)qf[sub][ks][j] * c_log2);
+  }
+
   int nk_eff = a.nk;
   if (CAUSAL) {
     const int qhi = q_blk + 128;
@@ -97,7 +113,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float c_log2 = a.scale * LOG2E;
   half8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
@@ -151,11 +166,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
         kf0[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((0 + fg) ^ swz128(r)) << 3));
         kf1[t] = *reinterpret_cast<const half8*>(Kt + r * 64 + (((4 + fg) ^ swz128(r)) << 3));
       }
-      const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 cinit[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float c0 = (LAZY && m_run[s] != -INFINITY) ? -m_run[s] : 0.f;  // LAZY: m_run is kept in the scaled log2 domain
+        cinit[s] = f32x4{c0, c0, c0, c0};
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0[t], qf[s][0], zero, 0, 0, 0);
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf0[t], qf[s][0], cinit[s], 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -210,6 +230,34 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
     for (int s = 0; s < 2; ++s) mx[s] = xor16_max(mx[s]);
 #pragma unroll
     for (int s = 0; s < 2; ++s) mx[s] = xor32_max(mx[s]);
+    if (LAZY) {
+      // st holds s' - m_eff with m_eff = m_run (0 while m_run is still -inf). Growth <=> the tile maximum of that is > 0
+      // (or anything finite arrives while m_run is -inf).
+      if (__any((mx[0] > 0.f) || (mx[1] > 0.f) || (m_run[0] == -INFINITY && mx[0] != -INFINITY) ||
+                (m_run[1] == -INFINITY && mx[1] != -INFINITY))) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          const float m_eff = (m_run[s] == -INFINITY) ? 0.f : m_run[s];
+          const float m_new = fmaxf(m_run[s], mx[s] + m_eff);
+          const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_eff;  // still to be subtracted from this tile's scores
+          const float alpha = (m_run[s] == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run[s] - m_new);
+          l_run[s] *= alpha;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[s][t][r] -= delta;
+          m_run[s] = m_new;
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[s][t][r] = __builtin_amdgcn_exp2f(st[s][t][r]);
+    } else {
     if (__any((mx[0] > m_run[0]) || (mx[1] > m_run[1]))) {  // some row's running max grows: textbook rescale
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
@@ -230,6 +278,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) st[s][t][r] = __builtin_amdgcn_exp2f(fmaf(st[s][t][r], c_log2, -mc[s]));
+    }
     // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
     half8 pf[2][2];
 #pragma unroll
