@@ -182,8 +182,9 @@ typedef struct {
   int32_t max_initial_timestamp_index; /* round(max_initial_timestamp / 0.02) = 50; < 0 = no limit            */
 } wca_decode_opts;
 
-/* Greedy ASR pre-pass for a micro-batch. Exactly one of mel_dev ([batch][n_mels][3000] f32, what whisper.decode
- * takes) and pcm_dev ([batch][pcm_stride] f32 + n_samples_host, log-mel computed on the device) is non-NULL.
+/* Greedy ASR pre-pass for a micro-batch. At most one of mel_dev ([batch][n_mels][3000] f32, what whisper.decode
+ * takes) and pcm_dev ([batch][pcm_stride] f32 + n_samples_host, log-mel computed on the device) is non-NULL; with
+ * both NULL the oldest undecoded state of wca_encode_batch is decoded.
  * initial_tokens_host [n_initial]: tokenizer.sot_sequence (every row starts with it).
  * suppress_mask_host [n_vocab] bytes: 1 = logit forced to -inf at every step (SuppressTokens list and, when the
  *   timestamp rules are on, <|notimestamps|>); blank_mask_host [n_vocab] (nullable): 1 = -inf at the first sampled
@@ -193,7 +194,16 @@ typedef struct {
  * sum_logprob_host [batch] (nullable): GreedyDecoder's sum of log-probabilities of the sampled tokens.
  * The encoder output and cross-attention K/V of this batch stay in the engine: the next wca_align_batch_enqueue
  * for the same batch may pass pcm_dev = NULL to re-use them (the reference runs the encoder twice,
- * infer_ali.py:60 and timing.py:58). Synchronous; no wca_align_batch_enqueue may be pending. */
+ * infer_ali.py:60 and timing.py:58). Synchronous (returns with the tokens). A state that was decoded but not aligned
+ * is dropped when the next wca_greedy_decode starts. */
+/* Phase 1 alone (log-mel or a given mel -> encoder -> cross-attention K/V of every decoder layer), enqueued on the
+ * engine stream without a host sync. The encoded state is queued: wca_greedy_decode(mel_dev = pcm_dev = NULL) decodes
+ * the oldest undecoded one, wca_align_batch_enqueue(pcm_dev = NULL) consumes the oldest one. Two K/V slots exist, so
+ * the NEXT batch can be encoded while the current one is decoded and aligned (the decode loop and the alignment's
+ * phase 2 run on the engine's second stream). */
+int wca_encode_batch(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride,
+                     const int32_t* n_samples_host, int batch);
+
 int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride,
                       const int32_t* n_samples_host, int batch, const int32_t* initial_tokens_host, int n_initial,
                       const uint8_t* suppress_mask_host, const uint8_t* blank_mask_host, const wca_decode_opts* opts,

@@ -189,3 +189,44 @@ def test_decode_rejects_unsupported(pkg, small):
         decoding.decode(m, mel, decoding.DecodingOptions(language=None))
     with pytest.raises(NotImplementedError):
         decoding.decode(m, mel, decoding.DecodingOptions(language="en", temperature=0.2))
+
+
+def test_pipelined_encode_decode_align(pkg, small, fake_vocab):
+    """Two-deep pipeline of the ASR flow: batch 1 is ENCODED (wca_encode_batch, first stream) before batch 0 is decoded
+    and aligned (second stream). Tokens and jump frames must equal the one-batch-at-a-time results, and a third encode
+    while both K/V slots are live is refused."""
+    m, sd, dims = small
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims)
+    B = 2
+    batches = []
+    for k in range(2):
+        pcm = np.stack([syn.synth_audio(20 + 2 * k + b, n_samples=56000) for b in range(B)]).astype(np.float32)
+        batches.append((torch.from_numpy(pcm).cuda(), [56000] * B))
+    initial = list(tok.sot_sequence)
+    kw = dict(sample_len=6, eot=tok.eot, timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50)
+    text_tokens = [tok.encode(c)[0] for c in "ab cd"]
+    row = [*tok.sot_sequence, tok.no_timestamps, *text_tokens, tok.eot]
+    tokens = torch.tensor([row] * B, dtype=torch.int64, device="cuda")
+    o = m.make_opts(aggregation="topk", topk=3, sot_len=len(tok.sot_sequence), medfilt_width=3)
+    # ---- serial reference
+    serial = []
+    for pcm_d, ns in batches:
+        t, n, lp = m.greedy_decode(None, pcm_d, ns, initial, sup, blank, **kw)
+        j, _ = m.align_batch(None, None, tokens, [len(row)] * B, [170] * B, o)
+        serial.append((t.copy(), n.copy(), j.copy()))
+    # ---- pipelined
+    m.encode_batch(pcm=batches[0][0], n_samples=batches[0][1])
+    m.encode_batch(pcm=batches[1][0], n_samples=batches[1][1])
+    with pytest.raises(Exception):
+        m.encode_batch(pcm=batches[0][0], n_samples=batches[0][1])  # both slots hold undecoded / unconsumed states
+    piped = []
+    for k in range(2):
+        t, n, lp = m.greedy_decode(None, None, None, initial, sup, blank, batch=B, **kw)
+        j, _ = m.align_batch(None, None, tokens, [len(row)] * B, [170] * B, o)
+        piped.append((t, n, j))
+    for (t0, n0, j0), (t1, n1, j1) in zip(serial, piped):
+        assert np.array_equal(t0, t1) and np.array_equal(n0, n1) and np.array_equal(j0, j1)
+    # the ordinary path still works afterwards (slots were released by the fetches)
+    j2, _ = m.align_batch(batches[0][0], batches[0][1], tokens, [len(row)] * B, [170] * B, o)
+    assert np.array_equal(j2, serial[0][2])

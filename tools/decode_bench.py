@@ -41,3 +41,37 @@ t_long = min(run(S) for _ in range(2))
 per_step = (t_long - t_short) / (S - 4)
 print("B=%d: encoder+cross-KV+%d-step loop %.1f ms; %d-step loop %.1f ms -> %.3f ms per decode step (%.1f us per utterance-step)" %
       (B, 4, t_short, S, t_long, per_step, per_step * 1e3 / B), flush=True)
+
+# ---- the whole ASR-teacher flow (infer_ali.py --teacher asr): encode -> greedy decode -> alignment re-using the encoder
+# state, serial vs two-deep pipeline (next batch encoded on stream 1 while this one is decoded / aligned on stream 2)
+retok = importlib.import_module("whisper-char-alignment_amd.retokenize")
+row = [*tok.sot_sequence, tok.no_timestamps, *retok.encode(syn.synth_text(0, 64), tok, "char"), tok.eot]
+tokens = torch.tensor([row] * B, dtype=torch.int64, device="cuda")
+o = m.make_opts(aggregation="topk", topk=10, sot_len=len(tok.sot_sequence), medfilt_width=3)
+kw = dict(sample_len=S, eot=tok.eot, timestamp_begin=tok.timestamp_begin)
+NB = 4
+
+
+def serial():
+    for _ in range(NB):
+        m.greedy_decode(None, pcm, ns, list(tok.sot_sequence), sup, blank, **kw)
+        m.align_batch(None, None, tokens, [len(row)] * B, [500] * B, o)
+
+
+def pipelined():
+    m.encode_batch(pcm=pcm, n_samples=ns)
+    for k in range(NB):
+        if k + 1 < NB:
+            m.encode_batch(pcm=pcm, n_samples=ns)
+        m.greedy_decode(None, None, None, list(tok.sot_sequence), sup, blank, batch=B, **kw)
+        m.align_batch(None, None, tokens, [len(row)] * B, [500] * B, o)
+
+
+for name, fn in (("serial", serial), ("pipelined", pipelined)):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / NB
+    print("ASR-teacher flow, %s: %.1f ms per batch of %d (%d decode steps) = %.0f utt/s" % (name, dt * 1e3, B, S, B / dt), flush=True)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "wca_align_batch": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts), _pi32, _pi32]),
     "wca_align_batch_enqueue": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts)]),
     "wca_align_batch_fetch": (_i, [_vp, _i, _i, _i, _pi32, _pi32]),
+    "wca_encode_batch": (_i, [_vp, _vp, _vp, _i64, _pi32, _i]),
     "wca_greedy_decode": (_i, [_vp, _vp, _vp, _i64, _pi32, _i, _pi32, _i, _vp, _vp, C.POINTER(DecodeOpts), _pi32, _pi32, _pf]),
     "wca_test_decode_select": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(DecodeOpts), _vp, _vp]),
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <set>
 #include <string>
 #include <vector>
@@ -151,7 +152,13 @@ struct wca_engine {
   // greedy ASR pre-pass (wca_greedy_decode): self-attention K/V cache [L][2][B][T_max][d], token rows, masks, logits
   GrowBuf dec_cache, dec_tokens, dec_masks, dec_logits, dec_state;
   int* dec_done_host = nullptr;  // pinned: completion counter read back while the loop runs
-  bool enc_state_valid = false;  // encoder output / cross-K/V of the last wca_greedy_decode may be re-used by the next enqueue
+  // Encoded micro-batches (log-mel + encoder + cross-K/V done, recorded on `stream`) that no alignment has consumed
+  // yet: wca_encode_batch / wca_greedy_decode push, wca_align_batch_enqueue(pcm_dev = NULL) pops the oldest. A K/V
+  // slot stays busy from its encode until the alignment that consumed it has been fetched.
+  struct EncState { int slot; int batch; bool decoded; };
+  std::deque<EncState> enc_q;
+  bool slot_busy[2] = {false, false};
+  int res_kvslot[2] = {-1, -1};
   // results ring: up to 2 wca_align_batch_enqueue calls may be in flight before their _fetch
   int* res_host[2] = {nullptr, nullptr};  // pinned results staging
   size_t res_host_ints[2] = {0, 0};
@@ -619,7 +626,8 @@ int check_ready(wca_engine* e) {
 }
 
 // stage per-utterance metadata into the next device slot: rows = {n_samples, n_tok, n_frames, dtwN}
-int stage_meta(wca_engine* e, int B, const int32_t* a0, const int32_t* a1, const int32_t* a2, const int32_t* a3, int** dev_rows) {
+int stage_meta(wca_engine* e, int B, const int32_t* a0, const int32_t* a1, const int32_t* a2, const int32_t* a3, int** dev_rows,
+               hipStream_t s = nullptr) {
   const int slot = e->meta_slot;
   e->meta_slot = (e->meta_slot + 1) % META_SLOTS;
   int* h = e->meta_host + (size_t)slot * 4 * e->max_batch;
@@ -627,7 +635,7 @@ int stage_meta(wca_engine* e, int B, const int32_t* a0, const int32_t* a1, const
   const int32_t* src[4] = {a0, a1, a2, a3};
   for (int r = 0; r < 4; ++r)
     for (int b = 0; b < B; ++b) h[r * e->max_batch + b] = src[r] ? src[r][b] : 0;
-  HIPCHK(hipMemcpyAsync(dv, h, sizeof(int) * 4 * e->max_batch, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipMemcpyAsync(dv, h, sizeof(int) * 4 * e->max_batch, hipMemcpyHostToDevice, s ? s : e->stream));
   for (int r = 0; r < 4; ++r) dev_rows[r] = dv + r * e->max_batch;
   return WCA_OK;
 }
@@ -667,6 +675,53 @@ __global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ 
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t st = (size_t)gridDim.x * blockDim.x;
   for (; i < n; i += st) out[i] = (float)in[i];
+}
+
+// K/V slot for a new encode: a free one, else the slot of the oldest state that was decoded but never aligned
+// (a stand-alone wca_greedy_decode); -1 if both hold data that is still needed.
+int take_kv_slot(wca_engine* e) {
+  for (int sl = 0; sl < 2; ++sl)
+    if (!e->slot_busy[sl]) return sl;
+  for (auto it = e->enc_q.begin(); it != e->enc_q.end(); ++it)
+    if (it->decoded) {
+      const int sl = it->slot;
+      e->enc_q.erase(it);
+      return sl;
+    }
+  return -1;
+}
+
+// Phase 1 on `stream` for one micro-batch: log-mel (from PCM) or layout change (from a given mel), encoder, cross-K/V of
+// every decoder layer into K/V slot `slot`; records ev_kv[slot]. n_samples_dev is only needed with pcm_dev.
+int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int* n_samples_dev, int batch, int slot) {
+  const wca_model_dims& D = e->dims;
+  half_t* kvbuf = slot ? e->kv_alt : e->kv;
+  record(e, 0);
+  if (pcm_dev) {
+    int rc = run_logmel(e, pcm_dev, pcm_stride, n_samples_dev, batch, nullptr, true);
+    if (rc) return rc;
+  } else {
+    const size_t nel = (size_t)D.n_mels * N_FRAMES;
+    dim3 grid((unsigned)((nel + 255) / 256), batch);
+    hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
+    HIPCHK(hipGetLastError());
+  }
+  record(e, 1);
+  int rc = run_encoder(e, batch);
+  if (rc) return rc;
+  record(e, 2);
+  rc = run_cross_kv(e, batch, kvbuf);
+  if (rc) return rc;
+  record(e, 3);
+  HIPCHK(hipEventRecord(e->ev_kv[slot], e->stream));
+  return WCA_OK;
+}
+
+int check_pcm_lengths(const int32_t* n_samples_host, int batch, int64_t pcm_stride) {
+  for (int b = 0; b < batch; ++b)
+    if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
+      return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid (pad_or_trim to <= 480000 first)", b, n_samples_host[b]);
+  return WCA_OK;
 }
 
 int validate_lengths(int B, int n_tok_max, const int32_t* n_tok, const int32_t* max_frames, int* Fmax_out) {
@@ -1392,10 +1447,17 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int rc = check_ready(e);
   if (rc) return rc;
   if (!tokens_dev || !n_tok_host || !max_frames_host || !o) return fail(WCA_ERR_INVALID, "null argument");
-  const bool reuse_enc = (pcm_dev == nullptr);  // cross-K/V of this batch already sits in the K/V buffer (wca_greedy_decode)
-  if (reuse_enc && (!e->enc_state_valid || e->last_batch != batch))
-    return fail(WCA_ERR_STATE, "pcm_dev == NULL re-uses the encoder state of the preceding wca_greedy_decode of the same batch; there is none");
+  const bool reuse_enc = (pcm_dev == nullptr);  // consume the oldest encoded state (wca_encode_batch / wca_greedy_decode)
+  if (reuse_enc && (e->enc_q.empty() || e->enc_q.front().batch != batch))
+    return fail(WCA_ERR_STATE, "pcm_dev == NULL re-uses the oldest state left by wca_encode_batch / wca_greedy_decode for the same batch; there is none");
   if (!reuse_enc && !n_samples_host) return fail(WCA_ERR_INVALID, "null argument");
+  if (!reuse_enc && !e->enc_q.empty()) {
+    // a stand-alone decode may have left a decoded state behind; an undecoded one is still wanted by its owner
+    for (auto& st : e->enc_q)
+      if (!st.decoded) return fail(WCA_ERR_STATE, "an encoded batch is waiting for wca_greedy_decode / wca_align_batch_enqueue(pcm_dev = NULL)");
+    for (auto& st : e->enc_q) e->slot_busy[st.slot] = false;
+    e->enc_q.clear();
+  }
   if (e->enq_count - e->fetch_count >= 2) return fail(WCA_ERR_STATE, "two batches already in flight: call wca_align_batch_fetch first");
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   if (o->aggregation != WCA_AGGR_MEAN && o->aggregation != WCA_AGGR_TOPK) return fail(WCA_ERR_INVALID, "aggregation %d", o->aggregation);
@@ -1404,10 +1466,7 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int Fmax = 0;
   rc = validate_lengths(batch, n_tok_max, n_tok_host, max_frames_host, &Fmax);
   if (rc) return rc;
-  if (!reuse_enc)
-    for (int b = 0; b < batch; ++b)
-      if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
-        return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
+  if (!reuse_enc && (rc = check_pcm_lengths(n_samples_host, batch, pcm_stride))) return rc;
   const wca_model_dims& D = e->dims;
   const int LH = D.n_text_layer * D.n_text_head;
   const int Fpad = (Fmax + 3) & ~3;
@@ -1417,31 +1476,31 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     if (dn[b] < 0) dn[b] = 0;
   }
   int* rows[4];
-  rc = stage_meta(e, batch, reuse_enc ? nullptr : n_samples_host, n_tok_host, max_frames_host, dn.data(), rows);
+  // (re-use: the metadata is only read by phase 2, so it travels on that stream -- `stream` may already hold the next
+  // batch's phase 1, and an event recorded behind it would serialise this batch's phase 2 after it)
+  rc = stage_meta(e, batch, reuse_enc ? nullptr : n_samples_host, n_tok_host, max_frames_host, dn.data(), rows,
+                  reuse_enc ? e->stream2 : nullptr);
   if (rc) return rc;
-  // ---- phase 1 on `stream`: log-mel, encoder, cross-K/V of all decoder layers into this batch's K/V buffer.
-  // (The buffer was last read by the batch two enqueues ago, which has been fetched: at most 2 are in flight.)
-  const int bs = (int)(e->enq_count & 1);
+  // ---- phase 1 on `stream`: log-mel, encoder, cross-K/V of all decoder layers into a free K/V slot (a slot is busy
+  // from its encode until the alignment that read it has been fetched; at most 2 alignments are in flight), or the
+  // slot of the encoded state this call consumes.
+  int bs;
+  if (reuse_enc) {
+    bs = e->enc_q.front().slot;
+    e->enc_q.pop_front();
+    record(e, 0);
+    record(e, 1);
+    record(e, 2);
+    record(e, 3);
+  } else {
+    bs = take_kv_slot(e);
+    if (bs < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
+    e->slot_busy[bs] = true;
+    rc = run_phase1(e, nullptr, pcm_dev, pcm_stride, rows[0], batch, bs);
+    if (rc) return rc;
+  }
   half_t* kvbuf = bs ? e->kv_alt : e->kv;
   hipStream_t s2 = e->stream2;
-  record(e, 0);
-  if (!reuse_enc) {
-    rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
-    if (rc) return rc;
-  }
-  record(e, 1);
-  if (!reuse_enc) {
-    rc = run_encoder(e, batch);
-    if (rc) return rc;
-  }
-  record(e, 2);
-  if (!reuse_enc) {
-    rc = run_cross_kv(e, batch, kvbuf);
-    if (rc) return rc;
-  }
-  record(e, 3);
-  e->enc_state_valid = false;
-  HIPCHK(hipEventRecord(e->ev_kv[bs], e->stream));
   // ---- phase 2 on `stream2`: decoder with capture, head statistics, top-k, aggregation, DTW, D2H. These are
   // latency-bound kernels with few workgroups; on their own stream they overlap the NEXT batch's phase 1.
   HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
@@ -1499,8 +1558,33 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   e->res_batch[rs] = batch;
   e->res_ntok[rs] = n_tok_max;
   e->res_topk[rs] = k;
+  e->res_kvslot[rs] = bs;
   e->last_batch = batch;
   e->enq_count++;
+  return WCA_OK;
+}
+
+int wca_encode_batch(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host, int batch) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if ((mel_dev == nullptr) == (pcm_dev == nullptr)) return fail(WCA_ERR_INVALID, "pass exactly one of mel_dev / pcm_dev");
+  if (pcm_dev && !n_samples_host) return fail(WCA_ERR_INVALID, "null argument");
+  if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
+  if (pcm_dev && (rc = check_pcm_lengths(n_samples_host, batch, pcm_stride))) return rc;
+  const int slot = take_kv_slot(e);
+  if (slot < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
+  int* rows[4] = {nullptr, nullptr, nullptr, nullptr};
+  if (pcm_dev) {
+    rc = stage_meta(e, batch, n_samples_host, nullptr, nullptr, nullptr, rows);
+    if (rc) return rc;
+  }
+  e->slot_busy[slot] = true;
+  rc = run_phase1(e, mel_dev, pcm_dev, pcm_stride, rows[0], batch, slot);
+  if (rc) {
+    e->slot_busy[slot] = false;
+    return rc;
+  }
+  e->enc_q.push_back({slot, batch, false});
   return WCA_OK;
 }
 
@@ -1510,7 +1594,8 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
                       float* sum_logprob_host) {
   int rc = check_ready(e);
   if (rc) return rc;
-  if ((mel_dev == nullptr) == (pcm_dev == nullptr)) return fail(WCA_ERR_INVALID, "pass exactly one of mel_dev / pcm_dev");
+  if (mel_dev != nullptr && pcm_dev != nullptr) return fail(WCA_ERR_INVALID, "pass at most one of mel_dev / pcm_dev");
+  const bool have_input = (mel_dev != nullptr) || (pcm_dev != nullptr);
   if (!initial_tokens_host || !suppress_mask_host || !o || !tokens_out_host || !n_tokens_host) return fail(WCA_ERR_INVALID, "null argument");
   if (pcm_dev && !n_samples_host) return fail(WCA_ERR_INVALID, "null argument");
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
@@ -1521,34 +1606,34 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
     return fail(WCA_ERR_INVALID, "eot / timestamp_begin outside the vocabulary");
   for (int i = 0; i < n_initial; ++i)
     if (initial_tokens_host[i] < 0 || initial_tokens_host[i] >= D.n_vocab) return fail(WCA_ERR_INVALID, "initial token %d outside the vocabulary", i);
-  if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the pending wca_align_batch_enqueue results first");
-  if (pcm_dev)
-    for (int b = 0; b < batch; ++b)
-      if (n_samples_host[b] < 0 || n_samples_host[b] > 480000 || n_samples_host[b] > pcm_stride)
-        return fail(WCA_ERR_INVALID, "n_samples[%d]=%d invalid", b, n_samples_host[b]);
   const int V = D.n_vocab, dt = D.n_text_state, L = D.n_text_layer;
   const int T_max = n_initial + o->sample_len;
-  // ---- phase 1 on `stream` into the K/V buffer the next wca_align_batch_enqueue will use (it may re-use it: pcm_dev = NULL)
-  const int bs = (int)(e->enq_count & 1);
-  half_t* kvbuf = bs ? e->kv_alt : e->kv;
-  if (pcm_dev) {
-    int* rows[4];
-    rc = stage_meta(e, batch, n_samples_host, nullptr, nullptr, nullptr, rows);
-    if (rc) return rc;
-    rc = run_logmel(e, pcm_dev, pcm_stride, rows[0], batch, nullptr, true);
-    if (rc) return rc;
-  } else {
-    const size_t nel = (size_t)D.n_mels * N_FRAMES;
-    dim3 grid((unsigned)((nel + 255) / 256), batch);
-    hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
-    HIPCHK(hipGetLastError());
+  // ---- phase 1 on `stream` (unless an encoded state is waiting: wca_encode_batch); the state stays queued for the
+  // alignment (wca_align_batch_enqueue with pcm_dev = NULL)
+  // a state that was decoded but never aligned is stale once another decode starts (stand-alone whisper.decode use)
+  for (auto it = e->enc_q.begin(); it != e->enc_q.end();) {
+    if (it->decoded) {
+      e->slot_busy[it->slot] = false;
+      it = e->enc_q.erase(it);
+    } else {
+      ++it;
+    }
   }
-  rc = run_encoder(e, batch);
-  if (rc) return rc;
-  rc = run_cross_kv(e, batch, kvbuf);
-  if (rc) return rc;
-  HIPCHK(hipEventRecord(e->ev_kv[bs], e->stream));
-  // ---- the autoregressive loop on `stream2` (it shares the decoder scratch with phase 2 of the alignment)
+  if (have_input) {
+    rc = wca_encode_batch(e, mel_dev, pcm_dev, pcm_stride, n_samples_host, batch);
+    if (rc) return rc;
+  }
+  wca_engine::EncState* st = nullptr;
+  for (auto& q : e->enc_q)
+    if (!q.decoded) {
+      st = &q;
+      break;
+    }
+  if (!st || st->batch != batch) return fail(WCA_ERR_STATE, "no encoded batch of %d utterances is waiting to be decoded", batch);
+  const int bs = st->slot;
+  half_t* kvbuf = bs ? e->kv_alt : e->kv;
+  // ---- the autoregressive loop on `stream2` (it shares the decoder scratch with phase 2 of the alignment, which is
+  // ordered before it on that stream; phase 1 of the NEXT batch may run beside it on `stream`)
   hipStream_t s2 = e->stream2;
   HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
   HIPCHK(e->dec_cache.ensure(sizeof(half_t) * (size_t)L * 2 * batch * T_max * dt));
@@ -1620,7 +1705,7 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
     for (int i = 0; i < T_max; ++i) tokens_out_host[(size_t)b * T_max + i] = (i < n_have) ? toks[(size_t)b * T_max + i] : o->eot;
     if (sum_logprob_host) sum_logprob_host[b] = lp[b];
   }
-  e->enc_state_valid = true;
+  st->decoded = true;
   e->last_batch = batch;
   return WCA_OK;
 }
@@ -1636,6 +1721,8 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
   if (jump_frame_host) memcpy(jump_frame_host, e->res_host[rs], sizeof(int) * (size_t)batch * n_tok_max);
   if (sel_idx_host && e->res_topk[rs] > 0)
     memcpy(sel_idx_host, e->res_host[rs] + (size_t)batch * n_tok_max, sizeof(int) * (size_t)batch * topk);
+  if (e->res_kvslot[rs] >= 0) e->slot_busy[e->res_kvslot[rs]] = false;
+  e->res_kvslot[rs] = -1;
   e->fetch_count++;
   return WCA_OK;
 }

@@ -99,14 +99,15 @@ def _check_supported(options):
 
 
 @torch.no_grad()
-def decode(model, mel, options=DecodingOptions(), pcm=None, n_samples=None):
+def decode(model, mel, options=DecodingOptions(), pcm=None, n_samples=None, encoded_batch=None):
     """whisper.decode. mel: [n_mels, 3000] or [B, n_mels, 3000] f32 cuda tensor (or None with pcm [B, stride] f32 cuda +
-    n_samples, the log-mel then runs on the device). Returns DecodingResult or a list of them."""
+    n_samples, the log-mel then runs on the device; or neither with encoded_batch=B: decode the state queued by
+    model.encode_batch). Returns DecodingResult or a list of them."""
     _check_supported(options)
     single = mel is not None and mel.ndim == 2
     if single:
         mel = mel.unsqueeze(0)
-    B = mel.shape[0] if mel is not None else pcm.shape[0]
+    B = mel.shape[0] if mel is not None else (pcm.shape[0] if pcm is not None else int(encoded_batch))
     dims = model.dims
     tokenizer = get_tokenizer(model.is_multilingual, language=options.language, task=options.task, vocab_path=options.vocab_path)
     n_ctx = dims.n_text_ctx
@@ -119,7 +120,7 @@ def decode(model, mel, options=DecodingOptions(), pcm=None, n_samples=None):
         max_init = round(options.max_initial_timestamp / precision)
     tokens, n_tokens, sum_logprobs = model.greedy_decode(
         mel, pcm, n_samples, initial, sup, blank, sample_len=sample_len, eot=tokenizer.eot, timestamp_begin=tokenizer.timestamp_begin,
-        apply_timestamp_rules=not options.without_timestamps, max_initial_timestamp_index=max_init)
+        apply_timestamp_rules=not options.without_timestamps, max_initial_timestamp_index=max_init, batch=B)
     results = []
     for b in range(B):
         toks = [int(t) for t in tokens[b, len(initial):n_tokens[b]]]

@@ -243,13 +243,29 @@ class WhisperAMD:
             return None
         return self.fetch(B, n_max, opts)
 
+    def encode_batch(self, mel=None, pcm=None, n_samples=None):
+        """C ABI wca_encode_batch: enqueue log-mel/encoder/cross-K/V of a micro-batch (no host sync). The state is picked up
+        by greedy_decode(None, None, None, ..., batch=B) and by align_batch(pcm=None, ...)."""
+        self._bind_stream()
+        B = mel.shape[0] if mel is not None else pcm.shape[0]
+        if mel is not None:
+            mel = mel.contiguous().float()
+        _lib.check(self._lib.wca_encode_batch(self._h, _ptr(mel) if mel is not None else None, _ptr(pcm) if pcm is not None else None,
+                                              pcm.shape[1] if pcm is not None else 0,
+                                              _lib.i32_array(n_samples) if n_samples is not None else None, B))
+        if not hasattr(self, "_keep"):
+            import collections
+            self._keep = collections.deque(maxlen=3)
+        self._keep.append((mel, pcm))  # the kernels read these buffers asynchronously; up to two encodes are in flight
+        return B
+
     def greedy_decode(self, mel, pcm, n_samples, initial_tokens, suppress_mask, blank_mask, sample_len, eot, timestamp_begin,
-                      apply_timestamp_rules=True, max_initial_timestamp_index=50):
+                      apply_timestamp_rules=True, max_initial_timestamp_index=50, batch=None):
         """C ABI wca_greedy_decode. mel [B,n_mels,3000] f32 cuda XOR pcm [B,stride] f32 cuda (+ n_samples).
         Returns (tokens [B, n_initial+sample_len] int32, n_tokens [B] int32, sum_logprobs [B] f32) as numpy arrays; the
         encoder state stays in the engine for a following align_batch(pcm=None, ...)."""
         self._bind_stream()
-        B = mel.shape[0] if mel is not None else pcm.shape[0]
+        B = mel.shape[0] if mel is not None else (pcm.shape[0] if pcm is not None else int(batch))  # batch=: decode a state queued by encode_batch
         n_init = len(initial_tokens)
         T = n_init + int(sample_len)
         tokens = np.zeros((B, T), dtype=np.int32)

@@ -86,21 +86,35 @@ def infer_dataset(args):
     all_predictions = {}
     local_times = {}
 
-    def flush(batch):
-        nonlocal corrects, total_preds, total_gts
-        if not batch:
-            return
+    def upload(batch):
         smax = max(len(b["pcm"]) for b in batch)
         pcm = np.zeros((len(batch), smax), dtype=np.float32)
         for j, b in enumerate(batch):
             pcm[j, :len(b["pcm"])] = b["pcm"]
-        pcm_dev = torch.from_numpy(pcm).to(device)
-        n_samples = [len(b["pcm"]) for b in batch]
+        return torch.from_numpy(pcm).to(device), [len(b["pcm"]) for b in batch]
+
+    def start_asr(batch):
+        """--teacher asr, stage 1: enqueue log-mel + encoder + cross-K/V of this micro-batch (no host sync). It runs on the
+        engine's first stream while the PREVIOUS micro-batch is decoded and aligned on the second one."""
+        pcm_dev, n_samples = upload(batch)
+        model.encode_batch(pcm=pcm_dev, n_samples=n_samples)
+        return batch
+
+    def flush(batch, encoded=False):
+        nonlocal corrects, total_preds, total_gts
+        if not batch:
+            return
         reuse = False
         if args.teacher == "asr":
             # greedy ASR pre-pass (infer_ali.py:60-61); its encoder output is re-used by the alignment below
-            results = decode(model, None, asr_options, pcm=pcm_dev, n_samples=n_samples)
+            if not encoded:
+                start_asr(batch)
+            results = decode(model, None, asr_options, encoded_batch=len(batch))
             reuse = True
+            pcm_dev = n_samples = None
+        else:
+            pcm_dev, n_samples = upload(batch)
+        if reuse:
             for b, r in zip(batch, results):
                 transcription = remove_punctuation(r.text)  # infer_ali.py:64
                 try:
@@ -142,7 +156,7 @@ def infer_dataset(args):
                 total_gts += tp + fn
                 total_preds += tp + fp
 
-    pending = []
+    pending, in_flight = [], []
     t0 = time.time()
     for n in mine:
         audio, _mel, duration, texts, starts, ends, fid = dataset[n]
@@ -177,9 +191,21 @@ def infer_dataset(args):
         pending.append(dict(index=n, pcm=pcm, tokens=tokens, text_tokens=text_tokens, max_frames=int(max_frames), texts=texts,
                             starts=starts, ends=ends, fid=fid))
         if len(pending) == args.batch_size:
-            flush(pending)
+            if args.teacher == "asr":
+                # two-deep pipeline: encode this micro-batch, then decode + align the previous one beside it
+                start_asr(pending)
+                flush(in_flight, encoded=True)
+                in_flight = pending
+            else:
+                flush(pending)
             pending = []
-    flush(pending)
+    if args.teacher == "asr":
+        if pending:
+            start_asr(pending)
+        flush(in_flight, encoded=True)
+        flush(pending, encoded=True)
+    else:
+        flush(pending)
     elapsed = time.time() - t0
 
     corrects, total_preds, total_gts = _shard.allreduce_counters(corrects, total_preds, total_gts)
