@@ -214,3 +214,32 @@ def test_subword_tokenizer_with_vocabulary_file(fake_vocab):
         g.write(b"".join(f.readlines()[:100]))
     with pytest.raises(ValueError):
         tokmod.get_tokenizer(True, language="en", vocab_path=bad)
+
+
+def test_ami_dataset_wrapper(tmp_path):
+    """ami_kaldi.pkl format of the reference's README (README.md:64-71) -> the (audio, mel, duration, text, starts, ends, fid)
+    item tuple; RIFF WAV segment written by hand."""
+    import importlib
+    import pickle
+    import struct
+    import numpy as np
+    ds = importlib.import_module("whisper-char-alignment_amd.dataset")
+    pcm = (np.sin(np.arange(8000) * 0.05) * 8000).astype("<i2")
+    wav = tmp_path / "seg.wav"
+    data = pcm.tobytes()
+    wav.write_bytes(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 1, 16000, 32000, 2, 16) +
+                    b"data" + struct.pack("<I", len(data)) + data)
+    sid = "AMI_TS3003d_H03_MTD012ME_0255148_0255515"
+    pkl = tmp_path / "ami_kaldi.pkl"
+    pkl.write_bytes(pickle.dumps({sid: [("hello", 0.05, 0.2), ("", 0.2, 0.25), ("world", 0.25, 0.45)]}))
+    scp = tmp_path / "ami.scp"
+    scp.write_text("%s %s\n" % (sid, wav))
+    d = ds.AMI(str(scp), compute_mel=False, alignment_file=str(pkl))
+    assert len(d) == 1
+    audio, mel, duration, text, starts, ends, fid = d[0]
+    assert duration == 8000 and audio.shape[-1] == 480000 and mel is None and fid == sid
+    assert text == "hello world" and starts == [0.05, 0.25] and ends == [0.2, 0.45]
+    import pytest
+    scp.write_text("missing_segment %s\n" % wav)
+    with pytest.raises(KeyError):
+        ds.AMI(str(scp), compute_mel=False, alignment_file=str(pkl))

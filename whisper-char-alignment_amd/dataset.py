@@ -1,5 +1,6 @@
 """Corpus wrappers with the reference's names (dataset.py:14-122): TIMIT and LibriSpeech datasets driven
-by a Kaldi-style `.scp` list (`<fid> <path>` per line, README.md:55-62), plus Collate.
+by a Kaldi-style `.scp` list (`<fid> <path>` per line, README.md:55-62), plus Collate and an AMI wrapper for the
+`ami_kaldi.pkl` references the reference's README describes.
 
 Differences from the reference, all on the I/O side (the per-item tuple is unchanged):
   * audio is read lazily (the reference's TIMIT loads the whole corpus in __init__, dataset.py:26-36);
@@ -144,4 +145,33 @@ class LibriSpeech(_ScpDataset):
             words.append(item[0])
             starts.append(item[1])
             ends.append(item[2])
+        return audio, mel, duration, " ".join(words), starts, ends, fid
+
+
+class AMI(_ScpDataset):
+    """AMI long-form segments (BASELINE config 4). The reference publishes the Kaldi word alignments as `ami_kaldi.pkl`
+    (README.md:64-71): `{"AMI_TS3003d_H03_MTD012ME_0255148_0255515": [("w1", s1, e1), ("w2", s2, e2), ...], ...}` but this
+    branch of the reference has no dataset class for it (infer_ali.py:28 lists TIMIT and LibriSpeech only); this one follows
+    the LibriSpeech wrapper: scp lines `<segment id> <path/to/segment.wav>`, words / start / end seconds from the pickle
+    (empty words dropped), audio beyond 30 s trimmed."""
+
+    def __init__(self, scp_file="scp/ami.wav.scp", n_mels=80, device="cpu", model=None, compute_mel=True, alignment_file="ami_kaldi.pkl"):
+        super().__init__(n_mels, device, model, compute_mel)
+        import pickle
+        with open(alignment_file, "rb") as f:
+            ali = pickle.load(f)
+        with open(scp_file) as f:
+            for line in f:
+                parts = line.split()
+                if len(parts) >= 2:
+                    if parts[0] not in ali:
+                        raise KeyError("%s has no entry in %s" % (parts[0], alignment_file))
+                    self.items.append((parts[1], ali[parts[0]], parts[0]))
+
+    def __getitem__(self, i):
+        path, ali, fid = self.items[i]
+        audio, mel, duration = self._audio_and_mel(path)
+        words = [w for w, _, _ in ali if w != ""]
+        starts = [float(s) for w, s, _ in ali if w != ""]
+        ends = [float(e) for w, _, e in ali if w != ""]
         return audio, mel, duration, " ".join(words), starts, ends, fid

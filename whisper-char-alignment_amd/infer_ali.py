@@ -34,7 +34,7 @@ if __package__ in (None, ""):
 
 from . import shard as _shard  # noqa: E402
 from .audio import N_SAMPLES_PER_TOKEN as AUDIO_SAMPLES_PER_TOKEN  # noqa: E402
-from .dataset import TIMIT, LibriSpeech  # noqa: E402
+from .dataset import AMI, TIMIT, LibriSpeech  # noqa: E402
 from .engine import WhisperAMD, dims_for, MAX_FRAMES, MAX_LENGTH  # noqa: E402
 from .metrics import eval_n1, eval_n1_strict, get_seg_metrics  # noqa: E402
 from .retokenize import encode, remove_punctuation  # noqa: E402
@@ -43,7 +43,7 @@ from .audio import log_mel_spectrogram, pad_or_trim  # noqa: E402
 from .tokenizer import get_tokenizer  # noqa: E402
 from .decoding import DecodingOptions, decode  # noqa: E402
 
-DATASET = {"TIMIT": TIMIT, "LibriSpeech": LibriSpeech}
+DATASET = {"TIMIT": TIMIT, "LibriSpeech": LibriSpeech, "AMI": AMI}
 
 
 def load_model(args, device):
@@ -77,7 +77,10 @@ def infer_dataset(args):
     asr_options = DecodingOptions(language="en", vocab_path=args.vocab)
     if args.teacher == "asr" and args.vocab is None and not args.random_init:
         raise SystemExit("--teacher asr turns token ids back into text: pass --vocab <local multilingual.tiktoken>")
-    dataset = DATASET[args.dataset](args.scp, n_mels=args.n_mels, device=device, model=model, compute_mel=False)
+    extra = {"alignment_file": args.alignment_file} if args.alignment_file else {}
+    if extra and args.dataset == "TIMIT":
+        raise SystemExit("--alignment_file applies to LibriSpeech (ls_alignment_*.txt) and AMI (ami_kaldi.pkl)")
+    dataset = DATASET[args.dataset](args.scp, n_mels=args.n_mels, device=device, model=model, compute_mel=False, **extra)
     mine = _shard.shard_indices(len(dataset), rank, world, [dataset.duration_hint(i) for i in range(len(dataset))])
     opts = model.make_opts(aggregation=args.aggr, topk=args.topk, w_colnorm=args.w_colnorm, w_rownorm=args.w_rownorm,
                            w_coverage=args.w_coverage, sot_len=len(tokenizer.sot_sequence), medfilt_width=args.medfilt_width,
@@ -230,7 +233,7 @@ def infer_dataset(args):
 def parse_args(argv=None):
     p = argparse.ArgumentParser(description="Arguments for whisper-based forced alignments")
     p.add_argument("--model", type=str, default="medium")
-    p.add_argument("--dataset", type=str, default="TIMIT", choices=["TIMIT", "LibriSpeech"])
+    p.add_argument("--dataset", type=str, default="TIMIT", choices=["TIMIT", "LibriSpeech", "AMI"])
     p.add_argument("--scp", type=str, default="scp/test.wav.scp")
     p.add_argument("--output_dir", type=str, default="results", help="Path to the output directory", required=True)
     p.add_argument("--n_mels", type=int, default=80)
@@ -251,6 +254,7 @@ def parse_args(argv=None):
     p.add_argument("--random_init", action="store_true", help="seeded random weights (dry run without a checkpoint)")
     p.add_argument("--vocab", type=str, default=None, help="local tiktoken vocabulary file (subword mode / non-ASCII text)")
     p.add_argument("--batch_size", type=int, default=16, help="utterances per micro-batch on each GPU")
+    p.add_argument("--alignment_file", type=str, default=None, help="LibriSpeech ls_alignment_<split>.txt / AMI ami_kaldi.pkl")
     p.add_argument("--teacher", type=str, default="text", choices=["text", "asr"],
                    help="asr: greedy decode pre-pass gives the teacher text (the reference's behaviour); text: dataset transcript")
     return p.parse_args(argv)
