@@ -1497,7 +1497,10 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     if (bs < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
     e->slot_busy[bs] = true;
     rc = run_phase1(e, nullptr, pcm_dev, pcm_stride, rows[0], batch, bs);
-    if (rc) return rc;
+    if (rc) {
+      e->slot_busy[bs] = false;
+      return rc;
+    }
   }
   half_t* kvbuf = bs ? e->kv_alt : e->kv;
   hipStream_t s2 = e->stream2;

@@ -11,6 +11,8 @@
 // The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
 // W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
 // of one output row: the epilogue stores 32 B (f16) / 64 B (f32) per lane per row.
+#include <atomic>
+
 #include "gemm_epilogue.h"
 #include "kernels.h"
 #include "wca_common.h"
@@ -727,12 +729,17 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
   if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
   if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
+  int dev = 0;
+  {
     hipError_t e = hipGetDevice(&dev);
-    if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return e;
+  }
+  static std::atomic<int> n_cu_cache[32] = {};  // CUs per device ordinal
+  int n_cu = n_cu_cache[dev & 31].load(std::memory_order_relaxed);
+  if (n_cu == 0) {
+    hipError_t e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    n_cu_cache[dev & 31].store(n_cu, std::memory_order_relaxed);
   }
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
@@ -757,14 +764,16 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     block = dim3(256);
     shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
   }
+  // the dynamic-LDS limit is a per-device property of each kernel symbol: remembered per (symbol, device) so that several
+  // engines (one per GPU) in one process and concurrent host threads are served correctly
 #define WCA_LAUNCH_K(KERN, OM, G, S)                                                              \
   do {                                                                                            \
-    static bool attr_set = false;                                                                 \
-    if (!attr_set) {                                                                              \
+    static std::atomic<unsigned> attr_mask{0};                                                    \
+    if (!(attr_mask.load(std::memory_order_acquire) & (1u << (dev & 31)))) {                      \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S>),           \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
       if (e != hipSuccess) return e;                                                              \
-      attr_set = true;                                                                            \
+      attr_mask.fetch_or(1u << (dev & 31), std::memory_order_release);                            \
     }                                                                                             \
     hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
