@@ -92,10 +92,11 @@ def test_gemm_skinny(eng, lib, wca, M, N, K, mode):
 
 @pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
 @pytest.mark.parametrize("tile", [257])
-@pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024)])
+@pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024), (9500, 2560, 512), (11700, 1536, 1024)])
 def test_gemm_persistent_many_tiles(eng, lib, wca, M, N, K, mode, tile):
     """More 256x256 tiles than CUs: a workgroup walks several tiles, its operand stream, bias buffers and ring-slot
-    parity carry across tile boundaries (ragged M and N in the first shape). Reference: fp32 matmul of the same
+    parity carry across tile boundaries (ragged M and N in the first shape; 38 and 46 m-panels in the last two, so the
+    last supertile of the tile order is short). Reference: fp32 matmul of the same
     f16 operands on the GPU; tolerances = f16 output rounding (2^-11) resp. fp32 accumulation order."""
     g = torch.Generator().manual_seed(M + N + K)
     ad = (torch.randn(M, K, generator=g) * 0.5).half().cuda()
@@ -121,6 +122,32 @@ def test_gemm_persistent_many_tiles(eng, lib, wca, M, N, K, mode, tile):
         wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2 | (tile << 8)))
         torch.cuda.synchronize()
         torch.testing.assert_close(out, base + ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("name,N,K,mode", [("qkv", 3072, 1024, "f16"), ("fc1", 4096, 1024, "f16_gelu"), ("fc2", 1024, 4096, "accum")])
+def test_gemm_bench_sized_encoder_shapes(eng, lib, wca, name, N, K, mode):
+    """The encoder GEMMs at exactly the bench's size (64 utterances: M = 96000 rows, 375 m-panels = 46 supertiles of 8
+    + one of 7, 17-23 tiles per workgroup) against an fp32 matmul of the same f16 operands on the GPU."""
+    M = 96000
+    g = torch.Generator(device="cuda").manual_seed(7)
+    ad = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+    wd = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    bd = torch.randn(N, generator=g, device="cuda")
+    if mode == "accum":
+        out = torch.randn(M, N, generator=g, device="cuda")
+        ref = out + (ad.float() @ wd.float().T + bd)
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, 0, 2))
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, ref, rtol=3e-4, atol=3e-4)
+    else:
+        gelu = int(mode == "f16_gelu")
+        out = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ad), _vp(wd), _vp(bd), _vp(out), M, N, K, gelu, 0))
+        ref = ad.float() @ wd.float().T + bd
+        if gelu:
+            ref = torch.nn.functional.gelu(ref)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out.float(), ref, rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(2000, 768, 1024), (515, 1024, 4096), (4096, 256, 64)])
