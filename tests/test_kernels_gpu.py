@@ -222,6 +222,30 @@ def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
         torch.testing.assert_close(got, qk_ref[..., :cap_cols], rtol=1e-4, atol=1e-4)
 
 
+def test_attention_bench_sized_encoder(eng, lib, wca):
+    """Encoder self-attention at the bench's size (64 utterances x 16 heads x 1500 x 1500: 12288 workgroups over the
+    XCD-aware grid) against fp32 softmax(q k^T / 8) v computed on the GPU four utterances at a time."""
+    B, H, S = 64, 16, 1500
+    d = H * 64
+    g = torch.Generator(device="cuda").manual_seed(21)
+    q = torch.randn(B, S, d, generator=g, device="cuda").half()
+    k = torch.randn(B, S, d, generator=g, device="cuda").half()
+    v = torch.randn(B, S, d, generator=g, device="cuda").half()
+    q[:, S // 3, :64] *= 4.0
+    out = torch.full((B, S, d), float("nan"), dtype=torch.float16, device="cuda")
+    wca._lib.check(lib.wca_test_attention(eng._h, _vp(q), _vp(k), _vp(v), _vp(out), None, 0, 0, B, H, S, S, 0))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for b0 in range(0, B, 4):
+        qq = q[b0:b0 + 4].float().view(4, S, H, 64).transpose(1, 2)
+        kk = k[b0:b0 + 4].float().view(4, S, H, 64).transpose(1, 2)
+        vv = v[b0:b0 + 4].float().view(4, S, H, 64).transpose(1, 2)
+        p = torch.softmax(qq @ kk.transpose(-1, -2) * 0.125, dim=-1)
+        ref = (p @ vv).transpose(1, 2).reshape(4, S, d)
+        worst = max(worst, float((out[b0:b0 + 4].float() - ref).abs().max()))
+    assert worst <= 4e-3, worst  # P and the output are f16, Q is pre-scaled in f16: ~1e-3 relative
+
+
 def test_layernorm(eng, lib, wca):
     g = torch.Generator().manual_seed(3)
     for d in (384, 1024, 1280):
