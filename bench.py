@@ -74,7 +74,7 @@ def build_inputs(wca_pkg, syn, tok_mod, retok, args, n_batches, rank, world, dev
     return tok, batches
 
 
-def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod):
+def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod, oracle_times):
     """Oracle (CPU restatement of the reference pipeline, kind 'port') on a bounded sample."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
     cores = min(os.cpu_count() or 1, 16)
@@ -84,6 +84,7 @@ def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod):
     filt = audio_mod.mel_filters(dims.n_mels)
     n_samples = int(args.seconds * 16000)
     times = []
+    oracle_times.clear()
     for u in range(args.cpu_utts + 1):
         pcm = torch.from_numpy(syn.synth_audio(10_000 + u, n_samples))
         text = syn.synth_text(10_000 + u, args.chars)
@@ -92,14 +93,51 @@ def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod):
         tt = tokenizer_ref.encode_char(text, tok)
         tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
         w, _ = timing_ref.get_attentions(mel, tokens, ref, n_samples // 320, args.medfilt_width, 1.0)
-        timing_ref.force_align(w, tt, tok, "char", "topk", args.topk)
+        _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", args.topk)
         dt = time.perf_counter() - t0
+        oracle_times.append((10_000 + u, text, np.asarray(st), np.asarray(en)))
         if u > 0:
             times.append(dt)
     per = float(np.mean(times))
     return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "kind": "port",
             "sample": "%d utterances (after 1 warm-up) of the same synthetic workload, batch 1 serial like infer_ali.py, "
                       "PyTorch-CPU fp32 forward + oracle post-processing, %.2f s/utt" % (len(times), per)}
+
+
+def parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device):
+    """The utterances the CPU baseline just aligned, through the GPU path inside a FULL bench-sized micro-batch (so the
+    persistent GEMMs, the batched attention grid and the batched DTW run at exactly the timed configuration); compares
+    word start / end times with the oracle's. Not part of the timed region."""
+    n_samples = int(args.seconds * 16000)
+    ids = [u for u, _t, _s, _e in oracle_times]
+    ids = (ids * ((args.batch + len(ids) - 1) // len(ids)))[:args.batch]  # fill the batch by repetition
+    pcm = np.stack([syn.synth_audio(u, n_samples) for u in ids])
+    texts = {u: t for u, t, _s, _e in oracle_times}
+    rows, tts = [], []
+    for u in ids:
+        tt = retok.encode(texts[u], tok, "char")
+        tts.append(tt)
+        rows.append([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
+    n_max = max(len(r) for r in rows)
+    toks = np.full((len(rows), n_max), tok.eot, dtype=np.int64)
+    for j, r in enumerate(rows):
+        toks[j, :len(r)] = r
+    jump, _ = model.align_batch(torch.from_numpy(pcm).to(device), [n_samples] * len(ids), torch.from_numpy(toks).to(device),
+                                [len(r) for r in rows], [n_samples // 320] * len(ids), opts)
+    total = within = identical = 0
+    for j, u in enumerate(ids[:len(oracle_times)]):
+        _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
+        _u, _t, rst, ren = oracle_times[j]
+        for a, b in ((np.asarray(st), rst), (np.asarray(en), ren)):
+            if len(a) != len(b):
+                return {"utterances": len(oracle_times), "error": "word count differs"}
+            total += len(a)
+            within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
+            identical += int(np.sum(a == b))
+    # batch invariance: the repeated copies of an utterance inside the batch must give the same frames
+    invariant = all(np.array_equal(jump[j][:len(rows[j])], jump[j % len(oracle_times)][:len(rows[j])]) for j in range(len(ids)))
+    return {"utterances": len(oracle_times), "word_boundaries": total, "within_one_frame": within, "identical": identical,
+            "batch_invariant": bool(invariant), "tolerance": "one 20 ms encoder frame (north_star)"}
 
 
 def measured_traffic(args, dims):
@@ -230,7 +268,10 @@ def main():
             names = ["logmel", "encoder", "cross_kv", "decoder", "head_stats", "topk_aggregate", "dtw", "total"]
             print("stage ms/step (last step): " + ", ".join("%s=%.3f" % (n, v) for n, v in zip(names, stage_acc)), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod)
+            oracle_times = []
+            out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod, oracle_times)
+            # same utterances through the GPU path at the timed configuration, checked against the oracle's word times
+            out["cpu_baseline"]["parity"] = parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
