@@ -6,7 +6,8 @@ CPU restatement of the greedy ASR pre-pass the reference runs before alignment:
 The arithmetic lives in the third-party dependency openai-whisper (`whisper/decoding.py`; unpinned in the reference,
 >= v20240930), which is absent from /root/reference and from this container. PARITY UNPINNED:
 the published algorithm is restated below (SuppressBlank, SuppressTokens, ApplyTimestampRules, GreedyDecoder.update,
-DecodingTask._main_loop) and checked against hand-derived known answers in tests/test_oracle.py.
+DecodingTask._main_loop) and checked against hand-derived known answers and, for the timestamp rules, against the
+independent port in HuggingFace transformers (WhisperTimeStampLogitsProcessor) in tests/test_oracle.py.
 """
 import numpy as np
 import torch

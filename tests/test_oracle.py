@@ -305,3 +305,35 @@ def test_decoding_ref_greedy_update_and_blank():
     lg = torch.zeros(1, 6)
     sb.apply(lg, torch.tensor([[0, 1, 3]]))  # only at the first sampled position
     assert lg.abs().sum() == 0
+
+
+def test_decoding_ref_timestamp_rules_vs_hf_port():
+    """Independent cross-check of the restated ApplyTimestampRules: HuggingFace transformers ships its own port of the
+    upstream rule set (WhisperTimeStampLogitsProcessor). Same -inf pattern and values on random histories / logits with
+    Whisper's multilingual special-token ids. (HF is not the reference; this catches restatement slips.)"""
+    import types
+    import numpy as np
+    import torch
+    from transformers.generation.logits_process import WhisperTimeStampLogitsProcessor
+    d = _dref()
+    EOT, NOTS, TSB, V, SB = 50257, 50363, 50364, 51865, 3
+    cfg = types.SimpleNamespace(no_timestamps_token_id=NOTS, eos_token_id=EOT, bos_token_id=EOT, max_initial_timestamp_index=50)
+    hf = WhisperTimeStampLogitsProcessor(cfg, begin_index=SB)
+    mine = d.ApplyTimestampRules(TSB, EOT, NOTS, SB, 50)
+    rng = np.random.default_rng(0)
+    prompt = [50258, 50259, 50359]
+    histories = [[], [TSB + 5], [TSB + 5, 400], [TSB + 5, 400, 500, TSB + 40], [TSB + 5, 400, TSB + 40, TSB + 40],
+                 [TSB + 5, 400, TSB + 40, TSB + 40, 777], [TSB, TSB], [TSB + 1499]]
+    for h in histories:
+        for trial in range(3):
+            logits = torch.from_numpy(rng.standard_normal((2, V)).astype(np.float32) * 3)
+            if trial == 1:
+                logits[:, TSB:] += 5.0  # timestamp probability mass wins
+            if trial == 2:
+                logits[:, :TSB] += 5.0
+            ids = torch.tensor([prompt + h, prompt + h])
+            want = hf(ids, logits.clone())
+            got = logits.clone()
+            mine.apply(got, ids)
+            assert torch.equal(torch.isinf(got), torch.isinf(want)), (h, trial)
+            assert torch.equal(torch.nan_to_num(got, neginf=0.0), torch.nan_to_num(want, neginf=0.0))
