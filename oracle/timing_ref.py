@@ -11,7 +11,8 @@ dependency openai-whisper, restated from its published algorithm, SURVEY.md Appe
 Pinning: filter_attention / the aggregation / the jump->time arithmetic are checked against the REAL
 reference `timing.py` executed in the build container under stub modules (tests/golden/make_golden.py ->
 tests/golden/*.npz). median_filter / dtw have no upstream fixture offline: PARITY UNPINNED for those two,
-they are checked against hand-derived known answers and a brute-force path search instead.
+they are checked against hand-derived known answers, a brute-force path search and the independent ports of both
+functions in HuggingFace transformers (tests/test_oracle.py::test_dtw_and_median_vs_hf_ports).
 """
 import ctypes
 import os

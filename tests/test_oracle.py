@@ -337,3 +337,26 @@ def test_decoding_ref_timestamp_rules_vs_hf_port():
             mine.apply(got, ids)
             assert torch.equal(torch.isinf(got), torch.isinf(want)), (h, trial)
             assert torch.equal(torch.nan_to_num(got, neginf=0.0), torch.nan_to_num(want, neginf=0.0))
+
+
+def test_dtw_and_median_vs_hf_ports():
+    """whisper.timing.dtw_cpu / backtrace and median_filter are upstream arithmetic without a fixture offline; HuggingFace
+    transformers carries independent ports of both (used for its word timestamps). The oracle (C dtw, torch median) must
+    give identical paths -- including integer-valued and constant matrices, where every step is a tie -- and identical
+    medians."""
+    import numpy as np
+    import torch
+    from transformers.models.whisper.generation_whisper import _dynamic_time_warping, _median_filter
+    from oracle import timing_ref
+    rng = np.random.default_rng(5)
+    cases = [rng.standard_normal((7, 30)), rng.standard_normal((23, 64)), rng.integers(0, 3, (12, 40)).astype(np.float64),
+             np.zeros((5, 17)), rng.standard_normal((1, 9)), rng.standard_normal((9, 1)), rng.standard_normal((30, 30)),
+             np.round(rng.standard_normal((16, 50)), 1)]
+    for m in cases:
+        x = torch.from_numpy(m.astype(np.float32))
+        ti, tj = timing_ref.dtw(-x)
+        hti, htj = _dynamic_time_warping((-x).double().numpy())
+        assert np.array_equal(ti, np.asarray(hti)) and np.array_equal(tj, np.asarray(htj)), m.shape
+    for shape, w in (((2, 3, 11, 50), 7), ((1, 2, 5, 9), 3), ((1, 1, 4, 3), 7), ((3, 2, 6, 64), 1), ((1, 1, 2, 4), 9)):
+        a = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
+        assert torch.equal(timing_ref.median_filter(a, w), _median_filter(a, w)), (shape, w)
