@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=2, help="utterances timed by the CPU baseline (after 1 warm-up)")
+    ap.add_argument("--cpu-utts", type=int, default=4, help="utterances timed by the CPU baseline (after 1 warm-up): ~10-12 s of CPU work")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
     return ap.parse_args()
 
