@@ -197,7 +197,9 @@ def _attn_ref(q, k, v, H, causal):
 
 @pytest.mark.parametrize("B,H,nq,nk,causal,cap_cols", [
     (2, 3, 150, 200, 0, 0), (1, 2, 70, 70, 1, 0), (2, 6, 69, 1500, 0, 500), (1, 4, 448, 1500, 0, 1500),
-    (1, 2, 300, 300, 1, 0), (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0)])
+    (1, 2, 300, 300, 1, 0), (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0),
+    # one query row per (utterance, head): the greedy-decode kernel (cross-attention length, short / ragged caches, one key)
+    (3, 4, 1, 1500, 0, 0), (2, 6, 1, 37, 0, 0), (2, 2, 1, 1, 0, 0), (1, 3, 1, 227, 0, 0), (2, 2, 1, 1, 1, 0)])
 def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     g = torch.Generator().manual_seed(nq * 13 + nk)
     d = H * 64

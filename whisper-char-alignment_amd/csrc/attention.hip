@@ -349,6 +349,114 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// One-query attention (greedy-decode steps: nq = 1 per utterance and head). The tile kernel above would spend a
+// 128-row MFMA tile on one live row; this is a memory-bound stream over the head's K and V rows (1500 x 128 B each for
+// the cross-attention: 393 MB per decoder layer at batch 64) with plain VALU math. One workgroup per (utterance,
+// head); its four waves take a quarter of the keys each; inside a wave eight lanes share a key (8 dims of 16 bytes
+// per lane), so one wave instruction reads 8 key rows, and each 8-lane group keeps its own online-softmax state
+// (m, l, o[8 dims]). Groups and waves are merged at the end (log-sum-exp combine through shuffles, then LDS).
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
+  __shared__ float part[4][66];  // per wave: m, l, o[64]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int grp = lane >> 3, c = lane & 7;
+  const int bh = blockIdx.x;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const float c_log2 = a.scale * LOG2E;
+  const half_t* qp = a.Q + (long)b * a.q_bs + h * 64 + c * 8;
+  const half8 qh = *reinterpret_cast<const half8*>(qp);
+  float q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) q[j] = (float)qh[j] * c_log2;  // scores directly in the log2 domain
+  const half_t* Kb = a.K + (long)b * a.k_bs + h * 64 + c * 8;
+  const half_t* Vb = a.V + (long)b * a.v_bs + h * 64 + c * 8;
+  const int per_wave = ((a.nk + 3) / 4 + 7) & ~7;  // keys per wave, a multiple of the 8 keys of one step
+  const int k_lo = wave * per_wave;
+  const int k_hi = (k_lo + per_wave < a.nk) ? k_lo + per_wave : a.nk;
+  float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  constexpr int U = 4;  // key steps in flight per wave (32 keys, 8 KiB of K + V)
+  for (int k0 = k_lo; k0 < k_hi; k0 += 8 * U) {
+    half8 kf[U], vf[U];
+    bool live[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = k0 + u * 8 + grp;
+      live[u] = key < k_hi;
+      const int kc = live[u] ? key : a.nk - 1;
+      kf[u] = *reinterpret_cast<const half8*>(Kb + (long)kc * a.k_rs);
+      vf[u] = *reinterpret_cast<const half8*>(Vb + (long)kc * a.v_rs);
+    }
+    float sc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d = fmaf(q[j], (float)kf[u][j], d);
+      d += __shfl_xor(d, 1);
+      d += __shfl_xor(d, 2);
+      d += __shfl_xor(d, 4);
+      sc[u] = live[u] ? d : -INFINITY;
+    }
+    float mb = sc[0];
+#pragma unroll
+    for (int u = 1; u < U; ++u) mb = fmaxf(mb, sc[u]);
+    const float m_new = fmaxf(m, mb);
+    if (m_new != -INFINITY) {
+      const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_new);
+      l *= alpha;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] *= alpha;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float p = __builtin_amdgcn_exp2f(sc[u] - m_new);  // 0 for dead keys
+        l += p;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fmaf(p, (float)vf[u][j], o[j]);
+      }
+      m = m_new;
+    }
+  }
+  // merge the 8 key groups of the wave (lanes that hold the same dims: xor 8, 16, 32)
+#pragma unroll
+  for (int off = 8; off <= 32; off <<= 1) {
+    const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+    const float mn = fmaxf(m, m2);
+    const float a1 = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    const float a2 = (m2 == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m2 - mn);
+    l = l * a1 + l2 * a2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = o[j] * a1 + __shfl_xor(o[j], off) * a2;
+    m = mn;
+  }
+  if (lane < 8) {
+    if (lane == 0) {
+      part[wave][0] = m;
+      part[wave][1] = l;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[wave][2 + lane * 8 + j] = o[j];
+  }
+  __syncthreads();
+  if (tid < 64) {  // dim tid of the head
+    float mn = part[0][0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) mn = fmaxf(mn, part[w][0]);
+    float lt = 0.f, ov = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float aw = (part[w][0] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(part[w][0] - mn);
+      lt += part[w][1] * aw;
+      ov += part[w][2 + tid] * aw;
+    }
+    a.O[(long)b * a.o_bs + h * 64 + tid] = (half_t)(ov / lt);
+  }
+}
+
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
@@ -356,9 +464,13 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (a.nk <= 0) return hipErrorInvalidValue;
   if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;
   if (a.cap != nullptr && ((a.cap_ld % 4) != 0 || a.cap_ld < ((a.cap_cols + 3) & ~3))) return hipErrorInvalidValue;
+  const bool cap = a.cap != nullptr && a.cap_cols > 0;
+  if (a.nq == 1 && !cap && !a.dbg && (!a.causal || a.nk == 1)) {  // greedy-decode steps: the KV cache holds exactly the causal prefix
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(a.H * a.B), dim3(256), 0, s, a);
+    return hipGetLastError();
+  }
   dim3 grid(((a.nq + 127) / 128) * a.H * a.B), block(256);
   const size_t shmem = 3 * 2 * TILE * sizeof(half_t);  // 48 KiB
-  const bool cap = a.cap != nullptr && a.cap_cols > 0;
   if (a.dbg) {
     hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, block, shmem, s, a);
     return hipGetLastError();
