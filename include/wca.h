@@ -180,6 +180,7 @@ typedef struct {
   int32_t timestamp_begin;             /* tokenizer.timestamp_begin (<|0.00|>)                                */
   int32_t apply_timestamp_rules;       /* 1 = ApplyTimestampRules (without_timestamps False)                  */
   int32_t max_initial_timestamp_index; /* round(max_initial_timestamp / 0.02) = 50; < 0 = no limit            */
+  int32_t no_speech;                   /* tokenizer.no_speech (<|nospeech|>) for no_speech_prob; < 0 = skip   */
 } wca_decode_opts;
 
 /* Greedy ASR pre-pass for a micro-batch. At most one of mel_dev ([batch][n_mels][3000] f32, what whisper.decode
@@ -192,6 +193,8 @@ typedef struct {
  * tokens_out_host [batch][n_initial + sample_len] int32 (positions never reached hold eot);
  * n_tokens_host [batch]: row b's sampled tokens before its first EOT are tokens_out[b][n_initial : n_tokens[b]];
  * sum_logprob_host [batch] (nullable): GreedyDecoder's sum of log-probabilities of the sampled tokens.
+ * no_speech_prob_host [batch] (nullable; needs opts->no_speech >= 0): softmax probability of <|nospeech|> at the
+ *   <|startoftranscript|> position (DecodingResult.no_speech_prob).
  * The encoder output and cross-attention K/V of this batch stay in the engine: the next wca_align_batch_enqueue
  * for the same batch may pass pcm_dev = NULL to re-use them (the reference runs the encoder twice,
  * infer_ali.py:60 and timing.py:58). Synchronous (returns with the tokens). A state that was decoded but not aligned
@@ -207,7 +210,8 @@ int wca_encode_batch(wca_engine* e, const float* mel_dev, const float* pcm_dev, 
 int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride,
                       const int32_t* n_samples_host, int batch, const int32_t* initial_tokens_host, int n_initial,
                       const uint8_t* suppress_mask_host, const uint8_t* blank_mask_host, const wca_decode_opts* opts,
-                      int32_t* tokens_out_host, int32_t* n_tokens_host, float* sum_logprob_host);
+                      int32_t* tokens_out_host, int32_t* n_tokens_host, float* sum_logprob_host,
+                      float* no_speech_prob_host);
 
 /* Same pipeline, but only enqueues the work on the engine stream (no host sync; results stay in the engine's
  * pinned staging ring until wca_align_batch_fetch). Up to TWO batches may be in flight: _fetch returns the

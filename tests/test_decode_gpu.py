@@ -120,7 +120,9 @@ def test_greedy_decode_vs_oracle(pkg, small):
     mel = torch.stack([audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=m) for p in pcm]).cuda()
     initial = list(tok.sot_sequence)
     toks, n_tok, lps = m.greedy_decode(mel, None, None, initial, sup, blank, sample_len=sample_len, eot=tok.eot,
-                                       timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50)
+                                       timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50,
+                                       no_speech=tok.no_speech)
+    nsp = m.last_no_speech_prob.copy()
     assert toks.shape == (B, len(initial) + sample_len)
     assert (toks[:, :len(initial)] == np.array(initial)).all()
     # ---- oracle, teacher-forced along the GPU's choices
@@ -129,6 +131,10 @@ def test_greedy_decode_vs_oracle(pkg, small):
                                 [i for i in np.nonzero(sup)[0] if i != tok.no_timestamps], tok.encode(" "), True, 50)
     forced = torch.from_numpy(toks.astype(np.int64))
     _, _, per_step = dref.greedy_decode(ref, mel.cpu(), initial, filters, tok.eot, sample_len, forced=forced)
+    # no_speech_prob: softmax of the UNFILTERED logits at the <|sot|> position (DecodingTask._main_loop, i == 0)
+    sot_logits = ref.decoder(torch.tensor([initial] * B), ref.encoder(mel.cpu()))[0][:, 0]
+    want_nsp = sot_logits.float().softmax(-1)[:, tok.no_speech].numpy()
+    assert np.all(np.isfinite(nsp)) and np.allclose(nsp, want_nsp, rtol=0.05, atol=1e-9), (nsp, want_nsp)
     n_exact = n_total = 0
     tol = 0.05  # logits are O(1); f16 operands in a 2-layer model perturb them by ~1e-2
     for i, filt in enumerate(per_step):

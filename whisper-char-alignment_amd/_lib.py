@@ -34,7 +34,7 @@ class AlignOpts(C.Structure):
 
 class DecodeOpts(C.Structure):
     _fields_ = [("sample_len", C.c_int32), ("eot", C.c_int32), ("timestamp_begin", C.c_int32),
-                ("apply_timestamp_rules", C.c_int32), ("max_initial_timestamp_index", C.c_int32)]
+                ("apply_timestamp_rules", C.c_int32), ("max_initial_timestamp_index", C.c_int32), ("no_speech", C.c_int32)]
 
 
 AGGR_MEAN, AGGR_TOPK = 0, 1
@@ -67,7 +67,7 @@ SIGNATURES = {
     "wca_align_batch_enqueue": (_i, [_vp, _vp, _i64, _pi32, _vp, _i, _pi32, _pi32, _i, C.POINTER(AlignOpts)]),
     "wca_align_batch_fetch": (_i, [_vp, _i, _i, _i, _pi32, _pi32]),
     "wca_encode_batch": (_i, [_vp, _vp, _vp, _i64, _pi32, _i]),
-    "wca_greedy_decode": (_i, [_vp, _vp, _vp, _i64, _pi32, _i, _pi32, _i, _vp, _vp, C.POINTER(DecodeOpts), _pi32, _pi32, _pf]),
+    "wca_greedy_decode": (_i, [_vp, _vp, _vp, _i64, _pi32, _i, _pi32, _i, _vp, _vp, C.POINTER(DecodeOpts), _pi32, _pi32, _pf, _pf]),
     "wca_test_decode_select": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(DecodeOpts), _vp, _vp]),
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

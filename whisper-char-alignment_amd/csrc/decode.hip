@@ -182,7 +182,28 @@ __global__ __launch_bounds__(1024) void decode_select_kernel(DecodeSelectArgs a)
   }
 }
 
+// probs_at_sot[no_speech] of DecodingTask._main_loop (i == 0): softmax over the vocabulary of the logits at the <|sot|>
+// position, probability of the <|nospeech|> token; one workgroup per row.
+__global__ __launch_bounds__(1024) void token_prob_kernel(const float* __restrict__ logits, int ld, int n_vocab, int token,
+                                                          float* __restrict__ out) {
+  __shared__ float red[16];
+  const float* lg = logits + (long)blockIdx.x * ld;
+  float m = -INFINITY;
+  for (int v = threadIdx.x; v < n_vocab; v += blockDim.x) m = fmaxf(m, lg[v]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < n_vocab; v += blockDim.x) s += __expf(lg[v] - m);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[blockIdx.x] = __expf(lg[token] - m) / s;
+}
+
 }  // namespace
+
+hipError_t launch_token_prob(const float* logits, int ld, int n_vocab, int token, float* out, int B, hipStream_t s) {
+  if (token < 0 || token >= n_vocab) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(token_prob_kernel, dim3(B), dim3(1024), 0, s, logits, ld, n_vocab, token, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_embed_step(const int* tokens, int T_max, int t, const half_t* tok_emb, const float* pos_emb, float* x, int B, int d,
                              hipStream_t s) {

@@ -1594,7 +1594,7 @@ int wca_encode_batch(wca_engine* e, const float* mel_dev, const float* pcm_dev, 
 int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
                       int batch, const int32_t* initial_tokens_host, int n_initial, const uint8_t* suppress_mask_host,
                       const uint8_t* blank_mask_host, const wca_decode_opts* o, int32_t* tokens_out_host, int32_t* n_tokens_host,
-                      float* sum_logprob_host) {
+                      float* sum_logprob_host, float* no_speech_prob_host) {
   int rc = check_ready(e);
   if (rc) return rc;
   if (mel_dev != nullptr && pcm_dev != nullptr) return fail(WCA_ERR_INVALID, "pass at most one of mel_dev / pcm_dev");
@@ -1643,7 +1643,8 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
   HIPCHK(e->dec_tokens.ensure(sizeof(int) * (size_t)batch * T_max));
   HIPCHK(e->dec_masks.ensure((size_t)2 * V));
   HIPCHK(e->dec_logits.ensure(sizeof(float) * (size_t)batch * V));
-  HIPCHK(e->dec_state.ensure(sizeof(float) * batch + sizeof(int) * (size_t)T_max));
+  HIPCHK(e->dec_state.ensure(sizeof(float) * 2 * batch + sizeof(int) * (size_t)T_max));
+  const bool want_nsp = no_speech_prob_host != nullptr && o->no_speech >= 0 && o->no_speech < V;
   if (!e->dec_done_host) HIPCHK(hipHostMalloc((void**)&e->dec_done_host, sizeof(int) * 4, hipHostMallocDefault));
   std::vector<int32_t> init((size_t)batch * T_max, o->eot);
   for (int b = 0; b < batch; ++b)
@@ -1651,11 +1652,12 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
   int* tokens_dev = (int*)e->dec_tokens.p;
   unsigned char* masks = (unsigned char*)e->dec_masks.p;
   float* sum_lp = (float*)e->dec_state.p;
-  int* n_done = (int*)((char*)e->dec_state.p + sizeof(float) * batch);
+  float* nsp = sum_lp + batch;
+  int* n_done = (int*)((char*)e->dec_state.p + sizeof(float) * 2 * batch);
   HIPCHK(hipMemcpyAsync(tokens_dev, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, s2));
   HIPCHK(hipMemcpyAsync(masks, suppress_mask_host, V, hipMemcpyHostToDevice, s2));
   if (blank_mask_host) HIPCHK(hipMemcpyAsync(masks + V, blank_mask_host, V, hipMemcpyHostToDevice, s2));
-  HIPCHK(hipMemsetAsync(e->dec_state.p, 0, sizeof(float) * batch + sizeof(int) * (size_t)T_max, s2));
+  HIPCHK(hipMemsetAsync(e->dec_state.p, 0, sizeof(float) * 2 * batch + sizeof(int) * (size_t)T_max, s2));
   HIPCHK(hipStreamSynchronize(s2));  // `init` is pageable host memory
   DecodeSelectArgs sel{};
   sel.logits = (const float*)e->dec_logits.p;
@@ -1676,8 +1678,10 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
   int steps = 0;
   for (int t = 0; t < T_max - 1; ++t) {
     const bool sample = (t >= n_initial - 1);
-    rc = run_decode_step(e, s2, kvbuf, tokens_dev, batch, t, T_max, sample);
+    const bool sot_logits = (t == 0 && want_nsp);  // probs_at_sot of DecodingTask._main_loop (sot_index = 0: no prompt)
+    rc = run_decode_step(e, s2, kvbuf, tokens_dev, batch, t, T_max, sample || sot_logits);
     if (rc) return rc;
+    if (sot_logits) HIPCHK(launch_token_prob((const float*)e->dec_logits.p, V, V, o->no_speech, nsp, batch, s2));
     if (!sample) continue;
     sel.cur_len = t + 1;
     HIPCHK(launch_decode_select(sel, batch, s2));
@@ -1693,8 +1697,8 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
   }
   std::vector<int32_t> toks((size_t)batch * T_max);
   HIPCHK(hipMemcpyAsync(toks.data(), tokens_dev, sizeof(int) * toks.size(), hipMemcpyDeviceToHost, s2));
-  std::vector<float> lp(batch);
-  HIPCHK(hipMemcpyAsync(lp.data(), sum_lp, sizeof(float) * batch, hipMemcpyDeviceToHost, s2));
+  std::vector<float> lp(2 * (size_t)batch);
+  HIPCHK(hipMemcpyAsync(lp.data(), sum_lp, sizeof(float) * 2 * batch, hipMemcpyDeviceToHost, s2));
   HIPCHK(hipStreamSynchronize(s2));
   const int n_have = n_initial + steps;  // positions written so far
   for (int b = 0; b < batch; ++b) {
@@ -1707,6 +1711,7 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
     n_tokens_host[b] = n;  // tokens_out[b][n_initial : n] are the sampled tokens before the first EOT
     for (int i = 0; i < T_max; ++i) tokens_out_host[(size_t)b * T_max + i] = (i < n_have) ? toks[(size_t)b * T_max + i] : o->eot;
     if (sum_logprob_host) sum_logprob_host[b] = lp[b];
+    if (want_nsp) no_speech_prob_host[b] = lp[batch + b];
   }
   st->decoded = true;
   e->last_batch = batch;

@@ -84,6 +84,8 @@ struct DecodeSelectArgs {
   int* n_done;                         // [T_max] n_done[cur_len] += 1 for every row whose new token is EOT
 };
 hipError_t launch_decode_select(const DecodeSelectArgs& a, int B, hipStream_t s);
+// out[b] = softmax(logits[b])[token]  (no_speech_prob: the <|nospeech|> probability at the <|sot|> position)
+hipError_t launch_token_prob(const float* logits, int ld, int n_vocab, int token, float* out, int B, hipStream_t s);
 hipError_t launch_f32_to_f16(const float* in, half_t* out, size_t n, hipStream_t s);
 
 // ---------------------------------------------------------------- log-mel (logmel.hip)

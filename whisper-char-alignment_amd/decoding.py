@@ -45,7 +45,7 @@ class DecodingResult:
     tokens: List[int] = field(default_factory=list)
     text: str = ""
     avg_logprob: float = np.nan
-    no_speech_prob: float = np.nan  # not computed by this engine (the reference's callers never read it)
+    no_speech_prob: float = np.nan
     temperature: float = np.nan
     compression_ratio: float = np.nan
 
@@ -120,12 +120,15 @@ def decode(model, mel, options=DecodingOptions(), pcm=None, n_samples=None, enco
         max_init = round(options.max_initial_timestamp / precision)
     tokens, n_tokens, sum_logprobs = model.greedy_decode(
         mel, pcm, n_samples, initial, sup, blank, sample_len=sample_len, eot=tokenizer.eot, timestamp_begin=tokenizer.timestamp_begin,
-        apply_timestamp_rules=not options.without_timestamps, max_initial_timestamp_index=max_init, batch=B)
+        apply_timestamp_rules=not options.without_timestamps, max_initial_timestamp_index=max_init, batch=B,
+        no_speech=tokenizer.no_speech if tokenizer.no_speech is not None else -1)
+    no_speech_probs = model.last_no_speech_prob
     results = []
     for b in range(B):
         toks = [int(t) for t in tokens[b, len(initial):n_tokens[b]]]
         text = tokenizer.decode(toks).strip()
         results.append(DecodingResult(language=options.language, tokens=toks, text=text,
-                                      avg_logprob=float(sum_logprobs[b]) / (len(toks) + 1), temperature=options.temperature,
+                                      avg_logprob=float(sum_logprobs[b]) / (len(toks) + 1), no_speech_prob=float(no_speech_probs[b]),
+                                      temperature=options.temperature,
                                       compression_ratio=compression_ratio(text) if text else np.nan))
     return results[0] if single else results

@@ -260,10 +260,11 @@ class WhisperAMD:
         return B
 
     def greedy_decode(self, mel, pcm, n_samples, initial_tokens, suppress_mask, blank_mask, sample_len, eot, timestamp_begin,
-                      apply_timestamp_rules=True, max_initial_timestamp_index=50, batch=None):
+                      apply_timestamp_rules=True, max_initial_timestamp_index=50, batch=None, no_speech=-1):
         """C ABI wca_greedy_decode. mel [B,n_mels,3000] f32 cuda XOR pcm [B,stride] f32 cuda (+ n_samples).
         Returns (tokens [B, n_initial+sample_len] int32, n_tokens [B] int32, sum_logprobs [B] f32) as numpy arrays; the
-        encoder state stays in the engine for a following align_batch(pcm=None, ...)."""
+        encoder state stays in the engine for a following align_batch(pcm=None, ...). With no_speech >= 0 (the
+        <|nospeech|> token id) self.last_no_speech_prob [B] holds DecodingResult.no_speech_prob."""
         self._bind_stream()
         B = mel.shape[0] if mel is not None else (pcm.shape[0] if pcm is not None else int(batch))  # batch=: decode a state queued by encode_batch
         n_init = len(initial_tokens)
@@ -276,7 +277,8 @@ class WhisperAMD:
         if sup.shape[0] != self.dims.n_vocab or (blank is not None and blank.shape[0] != self.dims.n_vocab):
             raise ValueError("filter masks must have n_vocab entries")
         opts = _lib.DecodeOpts(int(sample_len), int(eot), int(timestamp_begin), 1 if apply_timestamp_rules else 0,
-                               int(max_initial_timestamp_index))
+                               int(max_initial_timestamp_index), int(no_speech))
+        nsp = np.full(B, np.nan, dtype=np.float32)
         if mel is not None:
             mel = mel.contiguous().float()
         _lib.check(self._lib.wca_greedy_decode(
@@ -284,7 +286,9 @@ class WhisperAMD:
             pcm.shape[1] if pcm is not None else 0, _lib.i32_array(n_samples) if n_samples is not None else None, B,
             _lib.i32_array(initial_tokens), n_init, sup.ctypes.data_as(C.c_void_p),
             blank.ctypes.data_as(C.c_void_p) if blank is not None else None, C.byref(opts),
-            tokens.ctypes.data_as(_lib._pi32), n_tok.ctypes.data_as(_lib._pi32), lp.ctypes.data_as(_lib._pf)))
+            tokens.ctypes.data_as(_lib._pi32), n_tok.ctypes.data_as(_lib._pi32), lp.ctypes.data_as(_lib._pf),
+            nsp.ctypes.data_as(_lib._pf) if no_speech >= 0 else None))
+        self.last_no_speech_prob = nsp
         return tokens, n_tok, lp
 
     def decode(self, mel, options=None):
