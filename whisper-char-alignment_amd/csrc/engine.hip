@@ -1,5 +1,6 @@
 // libwca.so engine: weight residency, activation arena, forward orchestration and the C ABI of
-// include/wca.h.  One engine = one MI355X = one HIP stream = one host thread.
+// include/wca.h.  One engine = one MI355X = one host thread; two HIP streams (phase 1: log-mel, encoder, cross-K/V;
+// phase 2: decoder / greedy decode loop, post-processing, DTW, D2H) with two cross-K/V slots between them.
 //
 // Data layout in HBM (per engine, B = max_batch, d = n_state, L = decoder layers):
 //   weights   f16 [N][K] row-major (torch Linear layout), q/k/v fused to [3d][d]; the cross-attention
@@ -8,7 +9,8 @@
 //             [d][tap*C + c] so the conv stem is a GEMM over overlapping time-major windows.
 //   residual  f32 [B*1500][d] (encoder), f32 [B*n][d] (decoder); GEMM operands are f16.
 //   capture   f32 [B][L*H][n_max][Fpad]  pre-softmax cross-attention logits (timing.py:50-55)
-//   weights_ws f32 [B][L*H][n_max][Fmax] filtered+softmaxed maps (timing.py:63-66)
+//   weights_ws f32 [B][L*H][n_max][Fmax] filtered+softmaxed maps (timing.py:63-66; step-by-step API only)
+//   decode    f16 self-attention K/V cache [L][2][B][T_max][d], int32 token rows, fp32 logits [B][n_vocab]
 #include <hip/hip_runtime.h>
 
 #include <cmath>

@@ -3,10 +3,15 @@
 //
 //   C[m][n] = epi( sum_k A[m][k] * W[n][k] + bias[n] )
 //
-// Tile 128 x 128 x 64 per 256-thread workgroup (4 waves, 2x2, 64x64 per wave),
-// v_mfma_f32_16x16x32_f16, operands staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4)
-// into an XOR-swizzled [row][64] f16 image (swizzle applied on the per-lane SOURCE address, read
-// back with the same XOR), double buffered, one barrier per K tile.
+// Four kernels, chosen by launch_gemm:
+//   gemm256p_f16_kernel   persistent, software-pipelined 256 x 256 x 64 tile (8 waves): every large GEMM with a flat A
+//                         operand -- the encoder's QKV / out / fc1 / fc2, the fused cross-K/V projection, the logits
+//   gemm256_f16_kernel    same tile, two barriers per K tile, pointer DMA: the batch-strided conv-stem operands
+//   gemm_f16_kernel       128 x 128 x 64 tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave), two workgroups
+//                         per CU: GEMMs with fewer than ~192 big tiles (teacher-forced decoder, small batches)
+//   gemm_skinny_f16_kernel  M <= 64 rows, weight streaming without LDS staging: the greedy-decode steps
+// All use v_mfma_f32_16x16x32_f16 with fp32 accumulation; the tile kernels stage operands HBM -> LDS by LDS-DMA into an
+// XOR-swizzled [row][64] f16 image (swizzle applied on the per-lane SOURCE address, read back with the same XOR).
 //
 // The MFMA is issued with W as the A operand and the activation rows as the B operand, and the
 // W fragment rows are permuted, so that each lane ends up holding 16 CONSECUTIVE output columns
