@@ -84,3 +84,55 @@ for i in range(nf):
         print("force_align mismatch", L, H, n, F, k)
 print("filter_attention + force_align: %d cases, %d mismatches" % (nf, fbad), flush=True)
 print("FUZZ TOTAL mismatches:", bad + mbad + fbad)
+
+# ---- greedy-decode filter / update kernel along random oracle trajectories (timestamp pairing states reached naturally)
+import ctypes as C  # noqa: E402
+dref = importlib.import_module("oracle.decoding_ref")
+decoding = importlib.import_module("whisper-char-alignment_amd.decoding")
+_lib = importlib.import_module("whisper-char-alignment_amd._lib")
+tok2 = tk.get_tokenizer(True, language="en", task="transcribe")
+sup, blank = decoding.filter_masks(tok2, decoding.DecodingOptions(language="en"), 51865)
+V, Bd, T_max = 51865, 4, 40
+initial = list(tok2.sot_sequence)
+filters = dref.make_filters(len(initial), tok2.eot, tok2.timestamp_begin, tok2.no_timestamps,
+                            [i for i in np.nonzero(sup)[0] if i != tok2.no_timestamps], tok2.encode(" "), True, 50)
+supd, blankd = torch.from_numpy(sup).cuda(), torch.from_numpy(blank).cuda()
+o = _lib.DecodeOpts(224, tok2.eot, tok2.timestamp_begin, 1, 50, -1)
+eng._bind_stream()
+dbad = steps = 0
+g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+for traj in range(max(n_cases // 10, 5)):
+    tokens = torch.tensor([initial] * Bd, dtype=torch.long)
+    osum = torch.zeros(Bd)
+    td = torch.full((Bd, T_max), tok2.eot, dtype=torch.int32)
+    td[:, :len(initial)] = torch.tensor(initial, dtype=torch.int32)
+    td = td.cuda()
+    lpd = torch.zeros(Bd, device="cuda")
+    nd = torch.zeros(T_max, dtype=torch.int32, device="cuda")
+    for step in range(14):
+        logits = torch.randn(Bd, V, generator=g) * 3
+        mode = int(rng.integers(4))
+        if mode == 0:
+            logits[:, tok2.timestamp_begin:] += 6.0   # push towards timestamps
+        elif mode == 1:
+            logits[:, :tok2.eot] += 3.0               # push towards text
+        elif mode == 2:
+            logits[int(rng.integers(Bd)), tok2.eot] += 30.0  # end one row
+        cur_len = tokens.shape[1]
+        tokens, _done, _f = dref.select_step(logits, tokens, osum, filters, tok2.eot)
+        ld = logits.cuda()
+        _lib.check(eng._lib.wca_test_decode_select(eng._h, C.c_void_p(ld.data_ptr()), Bd, V, C.c_void_p(td.data_ptr()), T_max, cur_len,
+                                                   len(initial), C.c_void_p(supd.data_ptr()), C.c_void_p(blankd.data_ptr()), C.byref(o),
+                                                   C.c_void_p(lpd.data_ptr()), C.c_void_p(nd.data_ptr())))
+        torch.cuda.synchronize()
+        got = td[:, cur_len].cpu().long()
+        steps += 1
+        if not torch.equal(got, tokens[:, -1]):
+            dbad += 1
+            print("decode_select mismatch traj %d step %d" % (traj, step), got.tolist(), tokens[:, -1].tolist())
+            td[:, cur_len] = tokens[:, -1].int().cuda()  # continue along the oracle's trajectory
+    if not torch.allclose(lpd.cpu(), osum, rtol=1e-4, atol=1e-3):
+        dbad += 1
+        print("sum_logprob mismatch", lpd.cpu().tolist(), osum.tolist())
+print("decode_select: %d steps on %d trajectories, %d mismatches" % (steps, max(n_cases // 10, 5), dbad), flush=True)
+print("FUZZ TOTAL mismatches (all sections):", bad + mbad + fbad + dbad)
