@@ -38,7 +38,8 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[mt][nt][r] += bv[nt * 4 + r];
-      constexpr int NB = 3;  // row groups in flight (4 spills: the K loop's per-lane state stays live in a persistent kernel)
+      constexpr int NB = 3;  // row groups in flight (4 and 5 fit the register file too and measure the same: with three the
+                             // epilogue is already bound by the HBM traffic of the read-modify-write, not by its latency)
 #pragma unroll
       for (int base = 0; base < 8; base += NB) {
         f32x4 cv[NB][4];
