@@ -39,7 +39,10 @@ def main():
     lib = eng._lib
     M = B * 1500
     shapes = [("qkv", M, 3072, 1024, 0, 0), ("out", M, 1024, 1024, 0, 2), ("fc1", M, 4096, 1024, 1, 0), ("fc2", M, 1024, 4096, 0, 2),
-              ("crosskv", M, 49152, 1024, 0, 0), ("conv2", M, 1024, 3072, 1, 1), ("dec_fc1", B * 69, 4096, 1024, 1, 0)]
+              ("crosskv", M, 49152, 1024, 0, 0), ("conv2", M, 1024, 3072, 1, 1), ("dec_fc1", B * 69, 4096, 1024, 1, 0),
+              ("dec_qkv", B * 69, 3072, 1024, 0, 0), ("dec_out", B * 69, 1024, 1024, 0, 2), ("dec_fc2", B * 69, 1024, 4096, 0, 2)]
+    if os.environ.get("WCA_KB_ONLY"):
+        shapes = [sh for sh in shapes if sh[0].startswith(os.environ["WCA_KB_ONLY"])]
     for name, m, n, k, gelu, mode in shapes:
         a = (torch.randn(m, k, device="cuda") * 0.5).half()
         w = (torch.randn(n, k, device="cuda") * 0.05).half()
