@@ -92,7 +92,8 @@ def test_gemm_skinny(eng, lib, wca, M, N, K, mode):
 
 @pytest.mark.parametrize("mode", ["f16", "f16_gelu", "f32", "accum"])
 @pytest.mark.parametrize("tile", [257])
-@pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024), (9500, 2560, 512), (11700, 1536, 1024)])
+@pytest.mark.parametrize("M,N,K", [(10100, 2500, 256), (8192, 2560, 1024), (9500, 2560, 512), (11700, 1536, 1024),
+                                   (8500, 2560, 320), (8300, 2560, 64)])  # odd number of K tiles / one K tile: one tile per workgroup
 def test_gemm_persistent_many_tiles(eng, lib, wca, M, N, K, mode, tile):
     """More 256x256 tiles than CUs: a workgroup walks several tiles, its operand stream, bias buffers and ring-slot
     parity carry across tile boundaries (ragged M and N in the first shape; 38 and 46 m-panels in the last two, so the
