@@ -35,8 +35,8 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20, help="timed micro-batches per GPU (the two-deep pipeline drains once inside the timed region)")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
     ap.add_argument("--model", type=str, default="medium")
     ap.add_argument("--seconds", type=float, default=10.0)
