@@ -536,6 +536,8 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
       a.causal = 0;
       HIPCHK(launch_attention(a, s));
     }
+    // the last layer's cross-attention logits are captured by now: without logits nothing downstream is read
+    if (li == L - 1 && !logits_out) break;
     HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2, 2));
     HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, M, dt, 1e-5f, s));
     HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0, 2));
