@@ -468,11 +468,14 @@ int run_encoder(wca_engine* e, int B) {
 }
 
 // cross-attention K/V of every decoder layer in one GEMM: kv[b*1500 + t][(2l + {0,1})*dt + c]
-int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr) {
+// skip_last_v: the value projection of the LAST decoder layer (the final dt columns) is only read by that layer's
+// P.V product, whose result nobody uses when the caller wants the captured logits but no output logits.
+int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v = false) {
   if (!kvbuf) kvbuf = e->kv;
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
-  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, kvbuf, L * 2 * dt, B * N_CTX, L * 2 * dt, d, 0, 0, 3));
+  const int n_cols = L * 2 * dt - (skip_last_v ? dt : 0);
+  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, kvbuf, L * 2 * dt, B * N_CTX, n_cols, d, 0, 0, 3));
   return WCA_OK;
 }
 
@@ -697,7 +700,8 @@ int take_kv_slot(wca_engine* e) {
 
 // Phase 1 on `stream` for one micro-batch: log-mel (from PCM) or layout change (from a given mel), encoder, cross-K/V of
 // every decoder layer into K/V slot `slot`; records ev_kv[slot]. n_samples_dev is only needed with pcm_dev.
-int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int* n_samples_dev, int batch, int slot) {
+int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_t pcm_stride, const int* n_samples_dev, int batch, int slot,
+               bool skip_last_v = false) {
   const wca_model_dims& D = e->dims;
   half_t* kvbuf = slot ? e->kv_alt : e->kv;
   record(e, 0);
@@ -714,7 +718,7 @@ int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_
   int rc = run_encoder(e, batch);
   if (rc) return rc;
   record(e, 2);
-  rc = run_cross_kv(e, batch, kvbuf);
+  rc = run_cross_kv(e, batch, kvbuf, skip_last_v);
   if (rc) return rc;
   record(e, 3);
   HIPCHK(hipEventRecord(e->ev_kv[slot], e->stream));
@@ -1500,7 +1504,7 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     bs = take_kv_slot(e);
     if (bs < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
     e->slot_busy[bs] = true;
-    rc = run_phase1(e, nullptr, pcm_dev, pcm_stride, rows[0], batch, bs);
+    rc = run_phase1(e, nullptr, pcm_dev, pcm_stride, rows[0], batch, bs, /*skip_last_v=*/true);  // this path never asks for logits
     if (rc) {
       e->slot_busy[bs] = false;
       return rc;
