@@ -7,7 +7,9 @@ Parity status:
   * reference-owned code (timing.py filter_attention / aggregation / jump arithmetic, retokenize.py,
     metrics.py) -- PINNED against the real reference files executed under stub modules
     (tests/golden/make_golden.py -> tests/golden/*.npz).
-  * upstream openai-whisper arithmetic (log-mel, model forward, median_filter, dtw_cpu/backtrace) --
-    PARITY UNPINNED: the package is an unpinned, un-vendored dependency that is absent offline; restated
-    from its published algorithm and cross-checked against HuggingFace transformers' independent Whisper.
+  * upstream openai-whisper arithmetic (log-mel, model forward, median_filter, dtw_cpu/backtrace, and the greedy
+    decoding loop with its logit filters in decoding_ref.py) -- PARITY UNPINNED: the package is an unpinned,
+    un-vendored dependency that is absent offline; restated from its published algorithm and cross-checked against
+    HuggingFace transformers' independent implementations (model forward, feature extractor, and its ports of
+    dtw / median_filter / the timestamp logit rules: tests/test_oracle.py).
 """
