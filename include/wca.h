@@ -11,6 +11,7 @@
  *   wca_get_attentions     timing.py:45-67   get_attentions(): teacher-forced forward with every
  *                          cross-attention QK captured (timing.py:50-58), [:max_frames] slice,
  *                          median_filter, *qk_scale, softmax (timing.py:63-66); logits returned
+ *   wca_attention_weights  timing.py:63-66   the same post-processing on caller-supplied captured logits
  *   wca_median_filter      timing.py:65      whisper.timing.median_filter
  *   wca_filter_attention   timing.py:13-43   filter_attention(): head scores + tuple-ordered top-k
  *                          (+ metrics.py:99-111 coverage_penalty)
@@ -120,6 +121,13 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
                        const int32_t* n_tok_host, const int32_t* max_frames_host, int medfilt_width, float qk_scale,
                        float* weights_out_dev, float* logits_out_dev);
 
+/* The post-capture half of get_attentions (timing.py:63-66) on caller-supplied logits: qk_dev [L][H][n][ld] f32 (what
+ * the forward hooks collected, torch.cat'ed over layers; ld = row stride >= max_frames, 1500 in the reference) ->
+ * [..., :max_frames] slice, median_filter(medfilt_width), * qk_scale, softmax over frames ->
+ * weights_out_dev [L][H][n][max_frames] f32. */
+int wca_attention_weights(wca_engine* e, const float* qk_dev, int L, int H, int n, int ld, int max_frames,
+                          int medfilt_width, float qk_scale, float* weights_out_dev);
+
 /* in/out [rows][F] f32 device, reflect padding, width odd */
 int wca_median_filter(wca_engine* e, const float* in_dev, float* out_dev, int64_t rows, int F, int width);
 
@@ -140,10 +148,12 @@ int wca_force_align(wca_engine* e, const float* ws_dev, int L, int H, int n, int
  * median filter + softmax: weights of the given alignment heads (flat ids l*H + h) are normalised per head and frame
  * over the token axis, (w - mean) / std with population std (timing.py:159-160), averaged over the heads (:162),
  * sliced [sot_len:-1] (:163) and aligned with dtw(-matrix) (:165; the dtw_cpu tie rule is used).
- * ws_dev [L][H][n][F] as returned by wca_get_attentions; outputs as in wca_force_align. */
+ * ws_dev [L][H][n][F] as returned by wca_get_attentions; heads_host in the order of model.alignment_heads.indices().T
+ * (row-major over (l, h)); weights_norm_out_dev [n_heads][n][F] f32 device or NULL: the normalised weights, which
+ * the reference returns as its 4th value (timing.py:186); other outputs as in wca_force_align. */
 int wca_default_find_alignment(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const int32_t* heads_host,
-                                int n_heads, int sot_len, float* matrix_host, int32_t* text_idx_host,
-                                int32_t* time_idx_host, int32_t* path_len_host);
+                                int n_heads, int sot_len, float* weights_norm_out_dev, float* matrix_host,
+                                int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host);
 
 /* DTW on the NEGATED matrix exactly like `dtw(-matrix)`; matrix_host [N][M] f32 row-major.
  * text_idx_host / time_idx_host capacity N + M. */

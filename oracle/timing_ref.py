@@ -153,6 +153,15 @@ def get_attentions(mel, tokens, model_ref, max_frames, medfilt_width=7, qk_scale
     return weights, logits[0]
 
 
+def attention_weights(qks, max_frames, medfilt_width=7, qk_scale=1.0):
+    """The post-capture half of get_attentions (timing.py:63-66) on given logits: qks = list of per-layer
+    [1, H, n, S] tensors (what the forward hooks collected) or one [L, H, n, S] tensor."""
+    weights = torch.cat(list(qks)) if isinstance(qks, (list, tuple)) else torch.as_tensor(qks)
+    weights = weights[..., :max_frames]
+    weights = median_filter(weights, medfilt_width)
+    return (weights * qk_scale).softmax(dim=-1)
+
+
 # ------------------------------------------------------------------ timing.py:69-114
 def aggregate(ws, aggregation="mean", topk=-1, w_colnorm=1.0, w_rownorm=1.0, w_coverage=0.0):
     scores = None
@@ -198,6 +207,27 @@ def force_align(ws, tokens, tokenizer, aligned_unit_type="subword", aggregation=
 
 
 # ------------------------------------------------------------------ timing.py:157-165 (default_find_alignment, arithmetic part)
+def default_find_alignment(qk, heads, text_tokens, tokenizer, max_frames, medfilt_width=7, qk_scale=1.0):
+    """timing.py:116-186 after the forward: qk [L, H, n, S] captured logits (hooks keep outs[-1][0]), heads = list of
+    (l, h) in the order of model.alignment_heads.indices().T (row-major over the (L, H) mask). Returns the reference's
+    5-tuple (words, start_times, end_times, normalised weights [n_heads, n, F], None)."""
+    sot_len = len(tokenizer.sot_sequence)
+    qk = torch.as_tensor(qk)
+    weights = torch.stack([qk[l][h] for l, h in heads])          # :155
+    weights = weights[:, :, :max_frames]                          # :156
+    weights = median_filter(weights, medfilt_width)               # :157
+    weights = (weights * qk_scale).softmax(dim=-1)                # :158
+    std, mean = torch.std_mean(weights, dim=-2, keepdim=True, unbiased=False)
+    weights = (weights - mean) / std                              # :159-160
+    matrix = weights.mean(axis=0)[sot_len:-1]                     # :162-163
+    text_indices, time_indices = dtw(-matrix)                     # :165
+    words, word_tokens = tokenizer.split_to_word_tokens(list(text_tokens) + [tokenizer.eot])
+    if len(word_tokens) <= 1:
+        return [[], [], [], [], None]
+    start_times, end_times = jumps_to_times(text_indices, time_indices, word_tokens)
+    return words, start_times, end_times, weights, None
+
+
 def default_alignment_matrix(weights, heads, sot_len):
     """weights [L, H, n, F] already median filtered + softmaxed (timing.py:157-158); heads: list of (l, h).
     std/mean normalisation over the token axis, mean over heads, [sot:-1] slice (timing.py:159-163)."""

@@ -59,6 +59,25 @@ class CharTokenizer:
                 offset += len(dec)
         return words, word_tokens
 
+    def split_to_word_tokens(self, tokens):
+        """whisper.tokenizer.Tokenizer.split_to_word_tokens for a space-delimited language (upstream
+        split_tokens_on_spaces, restated from its published algorithm): a new word starts at a special
+        token, at a piece that starts with a space, at a piece that is pure punctuation, or first; other pieces are
+        appended to the current word. Used by the reference's default_find_alignment (timing.py:167)."""
+        subwords, subword_tokens_list = self.split_tokens_on_unicode(tokens)
+        words, word_tokens = [], []
+        for subword, subword_tokens in zip(subwords, subword_tokens_list):
+            special = subword_tokens[0] >= self.eot
+            with_space = subword.startswith(" ")
+            punctuation = subword.strip() in string.punctuation
+            if special or with_space or punctuation or len(words) == 0:
+                words.append(subword)
+                word_tokens.append(subword_tokens)
+            else:
+                words[-1] = words[-1] + subword
+                word_tokens[-1].extend(subword_tokens)
+        return words, word_tokens
+
 
 def encode_char(text, tokenizer):
     tokens = []

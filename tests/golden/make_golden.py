@@ -9,6 +9,12 @@ replaced by in-process stub modules:
     OWN arithmetic around them: head scores, tuple-ordered top-k, both aggregations, the [sot:-1] slice and
     the jump -> word-time arithmetic of force_align, plus retokenize.py and metrics.py verbatim)
   * a minimal byte-level tokenizer object (oracle.tokenizer_ref.CharTokenizer) stands in for whisper's.
+  * get_attentions (timing.py:45-67) and default_find_alignment (timing.py:116-186) run against a stub torch
+    nn.Module shaped like whisper.model.Whisper (hookable decoder.blocks[i].cross_attn whose forward returns
+    (out, qk), a sparse `alignment_heads` buffer, `dims.n_text_layer`, `device`): the QK logits are seeded
+    arrays, so what is pinned is the reference's hook wiring (outs[-1] / outs[-1][0]), cat / stack order,
+    [:max_frames] slice, median -> *qk_scale -> softmax order, std/mean normalisation, [sot:-1] slice, word
+    split and jump arithmetic, and the 5-tuple each function returns.
 Only arrays / strings (inputs and the reference's outputs) are stored; no reference source is copied.
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -43,6 +49,60 @@ def install_stubs():
     wa.HOP_LENGTH, wa.SAMPLE_RATE, wa.TOKENS_PER_SECOND = 160, 16000, 50
     w.model, w.timing, w.audio = wm, wt, wa
     sys.modules.update({"whisper": w, "whisper.model": wm, "whisper.timing": wt, "whisper.audio": wa})
+
+
+class _StubCrossAttn(torch.nn.Module):
+    """whisper.model.MultiHeadAttention stand-in: forward returns (out, qk) with a preset qk [1, H, n, S]."""
+
+    def __init__(self, qk):
+        super().__init__()
+        self.qk = qk
+
+    def forward(self, x, xa=None):
+        return x, self.qk
+
+
+class _StubBlock(torch.nn.Module):
+    def __init__(self, qk):
+        super().__init__()
+        self.cross_attn = _StubCrossAttn(qk)
+
+
+class _StubDecoder(torch.nn.Module):
+    def __init__(self, qks):
+        super().__init__()
+        self.blocks = torch.nn.ModuleList([_StubBlock(qk) for qk in qks])
+
+
+class StubWhisper(torch.nn.Module):
+    """The attributes timing.get_attentions / default_find_alignment touch on a whisper.model.Whisper."""
+
+    def __init__(self, qks, logits, alignment_heads=None):
+        super().__init__()
+        self.dims = types.SimpleNamespace(n_text_layer=len(qks))
+        self.decoder = _StubDecoder(qks)
+        self.logits = logits  # [n, V]
+        L, H = len(qks), qks[0].shape[1]
+        mask = torch.zeros(L, H, dtype=torch.bool)
+        for l, h in (alignment_heads or []):
+            mask[l, h] = True
+        self.register_buffer("alignment_heads", mask.to_sparse(), persistent=False)
+
+    @property
+    def device(self):
+        return torch.device("cpu")
+
+    def forward(self, mel, tokens):
+        assert mel.dim() == 3 and tokens.dim() == 2 and tokens.shape[-1] == self.logits.shape[0]
+        x = torch.zeros(1, tokens.shape[-1], 4)
+        for blk in self.decoder.blocks:
+            x = blk.cross_attn(x, None)[0]  # module __call__: the reference's forward hooks fire here
+        return self.logits[None]
+
+
+def _grid_randn(g, *shape, scale=3.0, step=1.0 / 32):
+    """Seeded logits on a coarse grid (compresses well; plenty of exact ties for the median)."""
+    return (torch.randn(*shape, generator=g) * scale / step).round() * step
 
 
 def main():
@@ -99,6 +159,51 @@ def main():
                               degenerate=not isinstance(matrix, torch.Tensor),
                               heads=[list(lh) for _, lh, _ in scores] if scores else None))
     meta["force_align"] = cases
+
+    # ---- get_attentions (timing.py:45-67) on the stub model
+    ga = []
+    for ci, (L, H, n, S, F, w, qs) in enumerate([(2, 3, 12, 96, 60, 7, 1.0), (3, 2, 9, 80, 80, 3, 1.0), (2, 2, 7, 64, 5, 1, 0.5),
+                                                  (1, 4, 6, 40, 3, 7, 1.0), (2, 2, 10, 72, 41, 5, 2.0)]):
+        g = torch.Generator().manual_seed(3000 + ci)
+        qks = [_grid_randn(g, 1, H, n, S) for _ in range(L)]
+        logits = torch.randn(n, 64, generator=g)
+        model = StubWhisper(qks, logits)
+        weights, out_logits = ref_timing.get_attentions(torch.zeros(80, 3000), torch.arange(n), model, tok, F, medfilt_width=w, qk_scale=qs)
+        assert tuple(weights.shape) == (L, H, n, F) and torch.equal(out_logits, logits)
+        arrays[f"ga_qk_{ci}"] = torch.cat(qks).numpy()
+        arrays[f"ga_w_{ci}"] = weights.numpy()
+        ga.append(dict(qk=f"ga_qk_{ci}", weights=f"ga_w_{ci}", max_frames=F, medfilt_width=w, qk_scale=qs,
+                       logits_passthrough=True))
+    meta["get_attentions"] = ga
+
+    # ---- default_find_alignment (timing.py:116-186) on the stub model
+    dfa = []
+    for ci, (text, L, H, S, F, w, heads) in enumerate([
+            ("artificial intelligence is for real", 3, 4, 120, 100, 7, [(1, 0), (2, 3), (2, 1)]),
+            ("it's a dog's life", 2, 2, 90, 64, 3, [(1, 1)]),
+            ("x", 2, 2, 40, 30, 7, [(0, 1), (1, 0)]),
+            ("", 2, 2, 40, 30, 7, [(0, 1), (1, 0)]),
+            ("ab cd ef", 4, 2, 64, 6, 7, [(3, 1), (0, 0), (2, 0), (1, 1)])]):
+        tt = ref_retokenize.encode(text, tok, "char")
+        n = len(tt) + 5
+        g = torch.Generator().manual_seed(4000 + ci)
+        qks = [_grid_randn(g, 1, H, n, S) for _ in range(L)]
+        logits = torch.randn(n, 51865, generator=g)
+        model = StubWhisper(qks, logits, heads)
+        out = ref_timing.default_find_alignment(model, tok, list(tt), torch.zeros(80, 3000), F, medfilt_width=w, qk_scale=1.0)
+        words, st, en, weights, last = out
+        assert last is None
+        rec = dict(qk=f"dfa_qk_{ci}", text=text, tokens=list(tt), max_frames=F, medfilt_width=w, heads=[list(h) for h in heads],
+                   heads_order=[list(map(int, lh)) for lh in model.alignment_heads.indices().T.tolist()],
+                   words=list(words), degenerate=not isinstance(weights, torch.Tensor))
+        arrays[f"dfa_qk_{ci}"] = torch.cat(qks).numpy()
+        if isinstance(weights, torch.Tensor):
+            assert tuple(weights.shape) == (len(heads), n, F)
+            arrays[f"dfa_w_{ci}"] = weights.numpy()
+            arrays[f"dfa_start_{ci}"] = np.asarray(st, dtype=np.float64)
+            arrays[f"dfa_end_{ci}"] = np.asarray(en, dtype=np.float64)
+        dfa.append(rec)
+    meta["default_find_alignment"] = dfa
 
     # ---- retokenize.py (char mode) on the stand-in tokenizer
     rt = []

@@ -36,12 +36,15 @@ def _worker(rank, world, port, n_items, q):
     local = {i: _fake_align(i) for i in mine}
     merged = shard.allgather_results(local, device=torch.device("cpu"))
     counters = shard.allreduce_counters(len(mine), 2 * len(mine), 3 * len(mine), device=torch.device("cpu"))
-    q.put((rank, mine, {k: (v[0].tolist(), v[1].tolist()) for k, v in merged.items()}, counters))
+    # the CLI's --save_prediction dicts (infer_ali.py:118-119): every rank's shard must reach rank 0
+    preds = shard.gather_predictions({i: dict(starts=[0.0], ends=[0.1 * i], texts=["w%d" % i], starts_hat=local[i][0], ends_hat=local[i][1],
+                                              predwords=["w%d" % i, "<|endoftext|>"], fids="utt%d" % i) for i in mine})
+    q.put((rank, mine, {k: (v[0].tolist(), v[1].tolist()) for k, v in merged.items()}, counters,
+           None if preds is None else {k: (v["fids"], v["ends_hat"].tolist()) for k, v in preds.items()}))
     dist.destroy_process_group()
 
 
-def test_shard_and_collate_world2():
-    world, n_items = 2, 23
+def _run_world(world, n_items):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -52,14 +55,32 @@ def test_shard_and_collate_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    owned = sorted(i for _, mine, _, _ in outs for i in mine)
+    owned = sorted(i for _, mine, _, _, _ in outs for i in mine)
     assert owned == list(range(n_items))  # a partition: every utterance exactly once
-    sizes = [len(mine) for _, mine, _, _ in outs]
+    sizes = [len(mine) for _, mine, _, _, _ in outs]
     assert max(sizes) - min(sizes) <= 1
     want = {i: tuple(a.tolist() for a in _fake_align(i)) for i in range(n_items)}
-    for _, _, merged, counters in outs:
+    for rank, _, merged, counters, preds in outs:
         assert merged == want  # every rank holds the full, identical collation
         assert counters == (n_items, 2 * n_items, 3 * n_items)
+        if rank == 0:  # len(pkl) == len(dataset): nothing is lost with one rank per GPU
+            assert sorted(preds) == list(range(n_items))
+            assert all(preds[i] == ("utt%d" % i, want[i][1]) for i in range(n_items))
+        else:
+            assert preds is None
+    return outs
+
+
+def test_shard_and_collate_world2():
+    _run_world(2, 23)
+
+
+def test_shard_and_collate_world4_ragged_and_empty_shard():
+    """n_items not divisible by the world size, and fewer items than ranks (a rank with an EMPTY shard must still take
+    part in both collectives and contribute nothing)."""
+    _run_world(4, 23)
+    outs = _run_world(4, 3)
+    assert sorted(len(mine) for _, mine, _, _, _ in outs) == [0, 1, 1, 1]
 
 
 def test_pack_roundtrip_and_single_process_paths():

@@ -68,31 +68,38 @@ def test_get_attentions_vs_oracle(wca, setup, medfilt, secs, chars):
 
 
 def test_force_align_word_times_within_one_frame(wca, setup):
-    """north_star tolerance: word start/end within one 20 ms frame of the CPU reference path."""
+    """north_star tolerance: EVERY word start/end within one 20 ms frame of the CPU reference path (fp32 forward,
+    timing.py:58) -- 12 utterances, char and top-k / mean aggregation."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
     syn, tk, rt, tm, audio = _mods()
     dims, sd, model, tok = setup
     ref = whisper_ref.WhisperRef(sd, dims)
     rtok = tokenizer_ref.CharTokenizer()
-    n_words = n_close = 0
-    for uid in range(4):
-        pcm, text, tt, tokens = _utt(syn, rt, tok, 20 + uid, 64000, 30)
+    n_words = n_ident = 0
+    offenders = []
+    for uid in range(12):
+        aggr, k = (("topk", 4), ("topk", 10), ("mean", -1))[uid % 3]
+        pcm, text, tt, tokens = _utt(syn, rt, tok, 20 + uid, 48000 + 16000 * (uid % 4), 20 + 5 * (uid % 5))
         max_frames = len(pcm) // 320
         mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
         w, _ = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, max_frames, medfilt_width=3)
-        words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=4)
+        words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", aggr, topk=k)
         rw, _ = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, max_frames, 3, 1.0)
-        rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 4)
+        rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", aggr, k)
         assert words == rwords
         # given the SAME matrix the GPU DTW is bit-exact
         ti, tj = timing_ref.dtw(-matrix)
         jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
         wb = np.pad(np.cumsum([len(t) for t in rt.split_tokens_on_spaces(tt + [tok.eot], tok, "char")[1][:-1]]), (1, 0))
         assert np.array_equal(st, (tj[jumps] / 50)[wb[:-1]]) and np.array_equal(en, (tj[jumps] / 50)[wb[1:]])
-        n_words += 2 * len(st)
-        n_close += int((np.abs(st - rst) <= 0.0201).sum() + (np.abs(en - ren) <= 0.0201).sum())
-    # end to end (f16 forward vs fp32 CPU forward): boundaries within one frame
-    assert n_close >= 0.9 * n_words, (n_close, n_words)
+        for a, b, kind in ((st, rst, "start"), (en, ren, "end")):
+            n_words += len(a)
+            n_ident += int((a == b).sum())
+            d = np.abs(np.asarray(a) - np.asarray(b))
+            offenders += [(uid, kind, i, float(a[i]), float(b[i])) for i in np.nonzero(d > 0.02 + 1e-9)[0]]
+    print("boundaries %d identical %d outside-one-frame %d" % (n_words, n_ident, len(offenders)))
+    # end to end (f16-operand forward vs fp32 CPU forward): every boundary within one frame
+    assert not offenders, offenders
 
 
 def test_align_batch_matches_stepwise_api(wca, setup):
@@ -133,29 +140,59 @@ def test_too_long_is_rejected(wca, setup):
 
 
 def test_north_star_config_parity_medium_dims(wca):
-    """whisper-medium dimensions (seeded random weights), 10 s audio, 64-char text, topk=10, medfilt 3:
-    f16-MFMA engine vs the fp32 CPU oracle. Word start/end times must be within one 20 ms frame."""
+    """The headline configuration at the bench's precision and batch size: whisper-medium dimensions, PEAKY seeded
+    weights (cross_qk_std=0.08: sharp maps, so f16 operand rounding can move heads / boundaries), 10 s audio, 64-char
+    text, topk=10, medfilt 3, through the FUSED wca_align_batch at B = 64 (persistent GEMMs, batched attention grid,
+    batched DTW exactly as timed by bench.py). 32 of the 64 utterances are also aligned by the fp32 CPU oracle: every
+    word boundary must be within one 20 ms frame; the selected heads must be the oracle's up to score noise."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
     syn, tk, rt, tm, audio = _mods()
     dims = wca.dims_for("medium")
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd)
+    B, n_ref = 64, 32
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
     ref = whisper_ref.WhisperRef(sd, dims)
     tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    pcm, text, tt, tokens = _utt(syn, rt, tok, 1, 160000, 64)
-    assert len(tokens) == 69
-    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    utts = [_utt(syn, rt, tok, 100 + u, 160000, 64) for u in range(B)]
+    assert all(len(u[3]) == 69 for u in utts)
+    pcm = np.stack([u[0] for u in utts])
+    tarr = np.asarray([u[3] for u in utts], dtype=np.int64)
+    opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
+    jump, sel = model.align_batch(torch.from_numpy(pcm).cuda(), [160000] * B, torch.from_numpy(tarr).cuda(), [69] * B, [500] * B, opts)
+    H = dims.n_text_head
+    total = ident = 0
+    offenders, head_match = [], 0
+    for i in range(n_ref):
+        p, text, tt, tokens = utts[i]
+        mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(p)), audio.mel_filters(80))
+        rw, _ = timing_ref.get_attentions(mel, torch.tensor(tokens), ref, 500, 3, 1.0)
+        rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
+        words, st, en = tm.words_from_jump_frames(jump[i], tt, tok, "char")
+        assert words == rwords
+        for a, b, kind in ((st, rst, "start"), (en, ren, "end")):
+            total += len(a)
+            ident += int((np.asarray(a) == np.asarray(b)).sum())
+            d = np.abs(np.asarray(a) - np.asarray(b))
+            offenders += [(i, kind, int(j), float(a[j]), float(b[j])) for j in np.nonzero(d > 0.02 + 1e-9)[0]]
+        # head selection: each GPU-selected head must score (in the fp32 oracle) at least the oracle's 10th best minus the
+        # f16-forward noise on a score (~1e-3 relative)
+        allref = {lh: s_ for s_, lh, _ in timing_ref.filter_attention(rw, dims.n_text_layer * H)[1]}
+        kth = rscores[0][0]
+        for hd in sel[i]:
+            assert allref[(int(hd) // H, int(hd) % H)] >= kth - 2e-3 * abs(kth), (i, int(hd), kth)
+        head_match += len(set(int(h) for h in sel[i]) & set(l * H + h for _, (l, h), _ in rscores))
+    print("medium B=64 fused: %d boundaries over %d utterances, identical %d, outside one frame %d, top-10 heads shared %d/%d"
+          % (total, n_ref, ident, len(offenders), head_match, 10 * n_ref))
+    assert not offenders, offenders
+    # step-by-step API at B = 1 on one utterance: maps and logits against the oracle (operand rounding visible here)
+    p, text, tt, tokens = utts[0]
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=model)
     w, logits = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
-    words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=10)
     rw, rlogits = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, 500, 3, 1.0)
-    rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
     assert tuple(w.shape) == (24, 16, 69, 500)
     assert (w.cpu() - rw).abs().max().item() < 1e-2          # measured 3e-3 (peaky maps, values up to 0.5)
     assert ((logits.cpu() - rlogits).abs().max() / rlogits.abs().max()).item() < 5e-3   # measured 8e-4
-    assert words == rwords
-    assert np.all(np.abs(st - rst) <= 0.0201) and np.all(np.abs(en - ren) <= 0.0201)
-    assert len(set(lh for _, lh, _ in scores) & set(lh for _, lh, _ in rscores)) >= 9
     del model
 
 
@@ -212,11 +249,18 @@ def test_default_find_alignment_vs_oracle(wca, setup):
     max_frames = len(pcm) // 320
     mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
     model.set_alignment_heads([(1, 0), (2, 3), (2, 1)])
-    words, st, en, matrix, _ = tm.default_find_alignment(model, tok, tt, mel, max_frames, medfilt_width=7)
-    # oracle on the engine's own weights: isolates the normalisation + DTW from the forward's f16 noise
+    assert model.alignment_heads == [(1, 0), (2, 1), (2, 3)]  # row-major, like alignment_heads.indices().T
+    words, st, en, weights, _ = tm.default_find_alignment(model, tok, tt, mel, max_frames, medfilt_width=7)
+    # oracle on the engine's own maps: isolates the normalisation + DTW from the forward's f16 noise
     w, _ = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, max_frames, medfilt_width=7)
-    ref_m = timing_ref.default_alignment_matrix(w.cpu(), model.alignment_heads, 3)
-    np.testing.assert_allclose(matrix.numpy(), ref_m.numpy(), rtol=2e-4, atol=2e-4)
+    hw = torch.stack([w.cpu()[l][h] for l, h in model.alignment_heads])
+    std, mean = torch.std_mean(hw, dim=-2, keepdim=True, unbiased=False)
+    ref_w = (hw - mean) / std
+    assert tuple(weights.shape) == (3, len(tokens), max_frames)     # the reference's 4th return (timing.py:186)
+    np.testing.assert_allclose(weights.cpu().numpy(), ref_w.numpy(), rtol=2e-4, atol=2e-5)
+    matrix = weights.cpu().mean(0)[3:-1]
+    np.testing.assert_allclose(matrix.numpy(), timing_ref.default_alignment_matrix(w.cpu(), model.alignment_heads, 3).numpy(),
+                               rtol=2e-4, atol=2e-5)
     ti, tj = timing_ref.dtw(-matrix)
     jumps = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
     _, word_tokens = tok.split_to_word_tokens(tt + [tok.eot])

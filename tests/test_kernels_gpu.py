@@ -359,11 +359,13 @@ def test_filter_attention(eng, lib, wca, shape, wts):
     full = timing_ref.filter_attention(A, shape[0] * H, *wts)[1]
     for s, (l, h), _ in full:
         assert abs(sc[l * H + h] - s) <= 2e-5 * max(1.0, abs(s))
-    # selection: identical unless two scores are closer than the reduction-order noise
-    ref_idx = [l * H + h for _, (l, h), _ in ref]
-    gaps = np.diff(sorted(s for s, _, _ in full))
-    if gaps.min() > 1e-4:
-        assert list(idx) == ref_idx
+    # selection, position by position: the reference's head, or one whose reference score is within the
+    # reduction-order noise of it (no blanket skip: every position is asserted)
+    allref = {l * H + h: s for s, (l, h), _ in full}
+    assert len(set(idx.tolist())) == len(idx)
+    for pos, (rs, (l, h), _) in enumerate(ref):
+        if int(idx[pos]) != l * H + h:
+            assert abs(allref[int(idx[pos])] - rs) <= 4e-5 * max(1.0, abs(rs)), (pos, int(idx[pos]), l * H + h)
 
 
 @pytest.mark.parametrize("aggr,topk", [("mean", -1), ("topk", 10), ("topk", 3)])

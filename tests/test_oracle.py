@@ -77,6 +77,45 @@ def test_coverage_penalty_matches_reference(gold):
     assert float(timing_ref.coverage_penalty(attn, 0.1)) == want[1]
 
 
+def test_attention_weights_match_reference_get_attentions(gold):
+    """timing.py:63-66 (cat -> [:max_frames] -> median_filter -> *qk_scale -> softmax) as executed by the REAL
+    get_attentions on a stub model whose hooked cross_attn modules return the stored logits."""
+    arrays, meta = gold
+    for case in meta["get_attentions"]:
+        qk = torch.from_numpy(arrays[case["qk"]])
+        w = timing_ref.attention_weights(qk, case["max_frames"], case["medfilt_width"], case["qk_scale"])
+        want = arrays[case["weights"]]
+        assert tuple(w.shape) == want.shape
+        # same torch ops on the same inputs: equal up to the host's softmax vectorisation (1 ulp of values <= 1)
+        np.testing.assert_allclose(w.numpy(), want, rtol=0, atol=2e-7)
+        # per-layer list form (what the hooks collect) == the concatenated form
+        H = qk.shape[1]
+        w2 = timing_ref.attention_weights([qk[l:l + 1] for l in range(qk.shape[0])], case["max_frames"], case["medfilt_width"],
+                                          case["qk_scale"])
+        assert torch.equal(w, w2) and H == w.shape[1]
+
+
+def test_default_find_alignment_matches_reference(gold):
+    """timing.py:116-186 executed by the REAL reference on the stub model: heads stacked in the row-major order of
+    alignment_heads.indices().T, std/mean normalisation (population std), [sot:-1] slice, DTW, split_to_word_tokens,
+    jump arithmetic, and the normalised weights as 4th return."""
+    arrays, meta = gold
+    tok = tokenizer_ref.CharTokenizer()
+    for ci, case in enumerate(meta["default_find_alignment"]):
+        qk = torch.from_numpy(arrays[case["qk"]])
+        heads = [tuple(h) for h in case["heads_order"]]
+        assert heads == sorted(tuple(h) for h in case["heads"])  # .indices() of the sparse mask: row-major
+        out = timing_ref.default_find_alignment(qk, heads, list(case["tokens"]), tok, case["max_frames"], case["medfilt_width"], 1.0)
+        if case["degenerate"]:
+            assert out == [[], [], [], [], None]
+            continue
+        words, st, en, weights, last = out
+        assert last is None and words == case["words"]
+        np.testing.assert_allclose(weights.numpy(), arrays[f"dfa_w_{ci}"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_array_equal(st, arrays[f"dfa_start_{ci}"])
+        np.testing.assert_array_equal(en, arrays[f"dfa_end_{ci}"])
+
+
 # ----------------------------------------------------------------------------- dtw: known answers
 def _brute_force_min_cost(x):
     """Minimum total cost over all monotone paths (moves: diag, down, right) from (0,0) to (N-1,M-1)."""

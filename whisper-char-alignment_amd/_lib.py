@@ -59,7 +59,8 @@ SIGNATURES = {
     "wca_median_filter": (_i, [_vp, _vp, _vp, _i64, _i, _i]),
     "wca_filter_attention": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _pf, _pi32, _pf]),
     "wca_force_align": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(AlignOpts), _pf, _pi32, _pi32, _pi32, _pi32, _pf]),
-    "wca_default_find_alignment": (_i, [_vp, _vp, _i, _i, _i, _i, _pi32, _i, _i, _pf, _pi32, _pi32, _pi32]),
+    "wca_default_find_alignment": (_i, [_vp, _vp, _i, _i, _i, _i, _pi32, _i, _i, _vp, _pf, _pi32, _pi32, _pi32]),
+    "wca_attention_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "wca_dtw": (_i, [_vp, _pf, _i, _i, _pi32, _pi32, _pi32]),
     "wca_dtw_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _pi32]),
     "wca_probe_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _pf, _pi32]),

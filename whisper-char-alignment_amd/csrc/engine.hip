@@ -1372,66 +1372,73 @@ int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int
   return WCA_OK;
 }
 
+int wca_attention_weights(wca_engine* e, const float* qk_dev, int L, int H, int n, int ld, int max_frames, int medfilt_width,
+                          float qk_scale, float* weights_out_dev) {
+  if (!e || !qk_dev || !weights_out_dev) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (int jr = join_phase2(e)) return jr;
+  const int LH = L * H;
+  if (L < 1 || H < 1 || n < 1) return fail(WCA_ERR_INVALID, "bad shape L=%d H=%d n=%d", L, H, n);
+  if (n > MAX_TOK) return fail(WCA_ERR_TOO_LONG, "n=%d > %d", n, MAX_TOK);
+  if (max_frames < 1 || ld < max_frames) return fail(WCA_ERR_INVALID, "max_frames=%d must be in [1, ld=%d]", max_frames, ld);
+  if (max_frames > N_CTX) return fail(WCA_ERR_TOO_LONG, "max_frames=%d > %d", max_frames, N_CTX);
+  if (medfilt_width < 1 || !(medfilt_width & 1) || medfilt_width > 33) return fail(WCA_ERR_INVALID, "medfilt_width must be odd and <= 33");
+  int32_t nt = n, nf = max_frames;
+  int* rows[4];
+  int rc = stage_meta(e, 1, nullptr, &nt, &nf, nullptr, rows);
+  if (rc) return rc;
+  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)LH * max_frames));
+  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)LH));
+  HeadStatsArgs h{};
+  h.qk = qk_dev;
+  h.qk_bs = 0;
+  h.qk_hs = (long)n * ld;
+  h.qk_ld = ld;
+  h.weights = weights_out_dev;
+  h.w_bs = 0;
+  h.n_tok = rows[1];
+  h.n_frames = rows[2];
+  h.n_tok_max = n;
+  h.n_frames_max = max_frames;
+  h.colnorm = (float*)e->colnorm.p;
+  h.scores = (float*)e->scores.p;
+  h.LH = LH;
+  h.B = 1;
+  h.medfilt_width = medfilt_width;
+  h.qk_scale = qk_scale;
+  h.w_col = 1.f;
+  h.w_row = 1.f;
+  h.w_cov = 0.f;
+  HIPCHK(launch_head_stats(h, e->stream));
+  return WCA_OK;
+}
+
 int wca_default_find_alignment(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, const int32_t* heads_host, int n_heads,
-                                int sot_len, float* matrix_host, int32_t* text_idx_host, int32_t* time_idx_host, int32_t* path_len_host) {
+                                int sot_len, float* weights_norm_out_dev, float* matrix_host, int32_t* text_idx_host,
+                                int32_t* time_idx_host, int32_t* path_len_host) {
   if (!e || !ws_dev || !heads_host || !path_len_host) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
   if (int jr = join_phase2(e)) return jr;
   const int LH = L * H, N = n - sot_len - 1;
   if (n_heads < 1) return fail(WCA_ERR_INVALID, "empty alignment head list");
+  if (L < 1 || H < 1 || n < 1 || n > MAX_TOK) return fail(WCA_ERR_INVALID, "bad shape L=%d H=%d n=%d", L, H, n);
+  if (F < 1 || F > N_CTX) return fail(WCA_ERR_TOO_LONG, "F=%d outside [1,%d]", F, N_CTX);
   if (sot_len < 0 || N < 1) return fail(WCA_ERR_INVALID, "n=%d leaves no rows after the [sot_len:-1] slice", n);
   for (int i = 0; i < n_heads; ++i)
     if (heads_host[i] < 0 || heads_host[i] >= LH) return fail(WCA_ERR_INVALID, "alignment head %d out of range", heads_host[i]);
-  int* rows[4];
-  HIPCHK(e->tmp1.ensure(sizeof(float) * (size_t)LH * F + sizeof(int) * (size_t)n_heads));
-  // column sums are needed next to the column norms: run the statistics pass with the colsum output enabled
-  if (L < 1 || H < 1 || n < 1 || n > MAX_TOK) return fail(WCA_ERR_INVALID, "bad shape L=%d H=%d n=%d", L, H, n);
-  if (F < 1 || F > N_CTX) return fail(WCA_ERR_TOO_LONG, "F=%d outside [1,%d]", F, N_CTX);
-  int32_t nt = n, nf = F, dn = N;
-  int rc = stage_meta(e, 1, nullptr, &nt, &nf, &dn, rows);
-  if (rc) return rc;
-  HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)LH * F));
-  HIPCHK(e->scores.ensure(sizeof(float) * (size_t)LH));
-  HeadStatsArgs h{};
-  h.qk = ws_dev;
-  h.qk_hs = (long)n * F;
-  h.qk_ld = F;
-  h.n_tok = rows[1];
-  h.n_frames = rows[2];
-  h.n_tok_max = n;
-  h.n_frames_max = F;
-  h.colnorm = (float*)e->colnorm.p;
-  h.colsum = (float*)e->tmp1.p;
-  h.scores = (float*)e->scores.p;
-  h.LH = LH;
-  h.B = 1;
-  h.medfilt_width = 1;
-  h.qk_scale = 1.f;
-  h.w_col = 1.f;
-  h.w_row = 1.f;
-  h.input_is_weights = 1;
-  HIPCHK(launch_head_stats(h, e->stream));
-  int* sel_dev = reinterpret_cast<int*>(reinterpret_cast<float*>(e->tmp1.p) + (size_t)LH * F);
+  // (w - mean) / std per head and frame over the token axis (two passes, population std), kept for the caller when it
+  // asks for it (the reference returns these normalised weights, timing.py:186), then the mean over the heads
+  const size_t norm_elems = (size_t)n_heads * n * F;
+  HIPCHK(e->tmp1.ensure(sizeof(int) * (size_t)n_heads + (weights_norm_out_dev ? 0 : sizeof(float) * norm_elems) + 256));
+  int* sel_dev = reinterpret_cast<int*>(e->tmp1.p);
+  float* norm = weights_norm_out_dev ? weights_norm_out_dev
+                                     : reinterpret_cast<float*>(reinterpret_cast<char*>(e->tmp1.p) + align_up(sizeof(int) * (size_t)n_heads, 256));
   HIPCHK(hipMemcpyAsync(sel_dev, heads_host, sizeof(int) * n_heads, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));  // heads_host is caller-owned pageable memory
+  HIPCHK(launch_stdmean_normalize(ws_dev, sel_dev, n_heads, n, F, norm, e->stream));
   HIPCHK(e->matrix.ensure(sizeof(float) * (size_t)n * F));
-  AggregateArgs g{};
-  g.weights = ws_dev;
-  g.w_bs = 0;
-  g.n_tok_max = n;
-  g.n_frames_max = F;
-  g.colnorm = (const float*)e->colnorm.p;
-  g.colsum = (const float*)e->tmp1.p;
-  g.sel_idx = sel_dev;
-  g.n_sel = n_heads;
-  g.LH = LH;
-  g.B = 1;
-  g.n_tok = rows[1];
-  g.n_frames = rows[2];
-  g.row_lo = sot_len;
-  g.row_hi_trim = 1;
-  g.matrix = (float*)e->matrix.p;
-  HIPCHK(launch_aggregate(g, e->stream));
-  rc = dtw_dev_common(e, (const float*)e->matrix.p, 1, N, F, false);
+  HIPCHK(launch_mean_heads(norm, n_heads, n, F, sot_len, 1, (float*)e->matrix.p, e->stream));
+  int rc = dtw_dev_common(e, (const float*)e->matrix.p, 1, N, F, false);
   if (rc) return rc;
   const int cap = N + F + 2;
   std::vector<int> path(2 * (size_t)cap);

@@ -117,7 +117,6 @@ struct HeadStatsArgs {
   const int* n_frames;     // [B] F per utterance (device)
   int n_tok_max, n_frames_max;  // strides of the dense `weights` layout: [head][n_tok_max][n_frames_max]
   float* colnorm;          // [B][LH][n_frames_max] per-head column L2 norms
-  float* colsum;           // optional [B][LH][n_frames_max] per-head column sums (default_find_alignment's std/mean)
   float* scores;           // [B][LH]
   float* rowstats;         // optional [B][LH][n_tok_max][2] = (row max of med*scale, sum of exp) so that selected
                            // heads can be re-materialised later without storing `weights`
@@ -143,11 +142,13 @@ struct AggregateArgs {
   const float* qk; long qk_bs; long qk_hs; int qk_ld;
   const float* rowstats;   // [B][LH][n_tok_max][2]
   int medfilt_width; float qk_scale;
-  // std_mean mode (timing.py:159-160, default_find_alignment): value = (w - mean_t) / std_t per head and frame,
-  // mean/std over the token axis (population std) from colsum / colnorm; colsum == nullptr => L2-norm mode
-  const float* colsum;
 };
 hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s);
+
+// default_find_alignment (timing.py:159-163): out[s][t][f] = (ws[sel[s]][t][f] - mean_t) / std_t (population std over
+// the n token rows), then matrix = mean over s of rows [row_lo, n - row_hi_trim). ws [LH][n][F], out [n_sel][n][F].
+hipError_t launch_stdmean_normalize(const float* ws, const int* sel_dev, int n_sel, int n, int F, float* out, hipStream_t s);
+hipError_t launch_mean_heads(const float* x, int n_sel, int n, int F, int row_lo, int row_hi_trim, float* matrix, hipStream_t s);
 
 // standalone median filter along the last axis with reflect padding (whisper.timing.median_filter)
 hipError_t launch_median_filter(const float* in, float* out, long rows, int F, int width, hipStream_t s);

@@ -200,7 +200,6 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
     const float sm_ = ((red_sum[f] + red_sum[Fmax + f]) + red_sum[2 * Fmax + f]) + red_sum[3 * Fmax + f];
     const float cn = sqrtf(sq);
     cn_out[f] = cn;
-    if (a.colsum) a.colsum[((long)b * a.LH + head) * Fmax + f] = sm_;
     cn_part += cn;
     cov_part += fmaxf(sm_, 0.5f);
   }
@@ -282,18 +281,11 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
   const int Fmax = a.n_frames_max;
   const float* W = a.weights ? a.weights + (long)b * a.w_bs : nullptr;
   const float* CN = a.colnorm + (long)b * a.LH * Fmax;
-  const float* CS = a.colsum ? a.colsum + (long)b * a.LH * Fmax : nullptr;
   float acc = 0.f;
   int cnt;
   auto contrib = [&](int hd) -> float {
     const float wv = W ? W[((long)hd * a.n_tok_max + t) * Fmax + f] : remat_weight(a, b, hd, t, f, F);
-    const float cn = CN[(long)hd * Fmax + f];
-    if (CS) {  // (w - mean) / std with population statistics over all n token rows
-      const float mean = CS[(long)hd * Fmax + f] / (float)n;
-      const float var = cn * cn / (float)n - mean * mean;
-      return (wv - mean) / sqrtf(fmaxf(var, 0.f));
-    }
-    return wv / cn;
+    return wv / CN[(long)hd * Fmax + f];
   };
   if (a.sel_idx) {
     cnt = 0;
@@ -308,6 +300,39 @@ __global__ __launch_bounds__(256) void aggregate_kernel(AggregateArgs a) {
     for (int hd = a.head_lo; hd < a.LH; ++hd) acc += contrib(hd);
   }
   a.matrix[((long)b * a.n_tok_max + (t - a.row_lo)) * Fmax + f] = acc / (float)cnt;
+}
+
+// default_find_alignment's normalisation (timing.py:159-160): per selected head and frame, (w - mean) / std over the
+// token axis with the population std, two passes like torch.std_mean. One thread per (head, frame) column; the
+// n <= 448 rows of a column are read three times (the second and third from L2). out [n_sel][n][F].
+__global__ __launch_bounds__(256) void stdmean_normalize_kernel(const float* __restrict__ ws, const int* __restrict__ sel, int n, int F,
+                                                                float* __restrict__ out) {
+  const int s = blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= F) return;
+  const float* col = ws + (long)sel[s] * n * F + f;
+  float sum = 0.f;
+  for (int t = 0; t < n; ++t) sum += col[(long)t * F];
+  const float mean = sum / (float)n;
+  float sq = 0.f;
+  for (int t = 0; t < n; ++t) {
+    const float d = col[(long)t * F] - mean;
+    sq = fmaf(d, d, sq);
+  }
+  const float sd = sqrtf(sq / (float)n);
+  float* o = out + (long)s * n * F + f;
+  for (int t = 0; t < n; ++t) o[(long)t * F] = (col[(long)t * F] - mean) / sd;
+}
+
+// matrix[t - row_lo][f] = mean over the n_sel heads of x[s][t][f], rows [row_lo, n - row_hi_trim)  (timing.py:162-163)
+__global__ __launch_bounds__(256) void mean_heads_kernel(const float* __restrict__ x, int n_sel, int n, int F, int row_lo, int row_hi_trim,
+                                                         float* __restrict__ matrix) {
+  const int t = row_lo + blockIdx.y;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n - row_hi_trim || f >= F) return;
+  float acc = 0.f;
+  for (int s = 0; s < n_sel; ++s) acc += x[((long)s * n + t) * F + f];
+  matrix[(long)(t - row_lo) * F + f] = acc / (float)n_sel;
 }
 
 __global__ __launch_bounds__(256) void median_filter_kernel(const float* __restrict__ in, float* __restrict__ out, long rows,
@@ -366,6 +391,19 @@ hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s) {
   if (rows <= 0) return hipSuccess;
   dim3 grid((a.n_frames_max + 255) / 256, rows, a.B), block(256);
   hipLaunchKernelGGL(aggregate_kernel, grid, block, 0, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_stdmean_normalize(const float* ws, const int* sel_dev, int n_sel, int n, int F, float* out, hipStream_t s) {
+  if (n_sel <= 0 || n <= 0 || F <= 0) return hipSuccess;
+  hipLaunchKernelGGL(stdmean_normalize_kernel, dim3((F + 255) / 256, n_sel), dim3(256), 0, s, ws, sel_dev, n, F, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_mean_heads(const float* x, int n_sel, int n, int F, int row_lo, int row_hi_trim, float* matrix, hipStream_t s) {
+  const int rows = n - row_lo - row_hi_trim;
+  if (n_sel <= 0 || rows <= 0 || F <= 0) return hipSuccess;
+  hipLaunchKernelGGL(mean_heads_kernel, dim3((F + 255) / 256, rows), dim3(256), 0, s, x, n_sel, n, F, row_lo, row_hi_trim, matrix);
   return hipGetLastError();
 }
 

@@ -66,6 +66,16 @@ class _ScpDataset(torch.utils.data.Dataset):
         except OSError:
             return 0
 
+    def read(self, i):
+        """(pcm f32 numpy [duration] (un-padded, trimmed to 30 s), duration, text, starts, ends, fid): what the fused
+        batch path needs, without the 30 s zero padding / log-mel of __getitem__. Thread-safe (reader pool)."""
+        path = self.items[i][0]
+        pcm, sr = _load_mono(path)
+        assert sr == self.sample_rate
+        duration = len(pcm)
+        text, starts, ends, fid = self._labels(i)
+        return pcm[:_audio.N_SAMPLES], duration, text, starts, ends, fid
+
     def _audio_and_mel(self, path):
         pcm, sr = _load_mono(path)
         assert sr == self.sample_rate
@@ -101,10 +111,14 @@ class TIMIT(_ScpDataset):
                     words.append(parts[2])
         return " ".join(words), starts, ends
 
-    def __getitem__(self, i):
-        path, wrd, fid = self.items[i]
+    def _labels(self, i):
+        _path, wrd, fid = self.items[i]
         text, starts, ends = self.process_text(wrd)
-        audio, mel, duration = self._audio_and_mel(path)
+        return text, starts, ends, fid
+
+    def __getitem__(self, i):
+        text, starts, ends, fid = self._labels(i)
+        audio, mel, duration = self._audio_and_mel(self.items[i][0])
         return audio, mel, duration, text, starts, ends, fid
 
 
@@ -135,9 +149,8 @@ class LibriSpeech(_ScpDataset):
             fid, path = line.split()[:2]
             self.items.append((path, labels[fid], ali[fid], fid))
 
-    def __getitem__(self, i):
-        path, _text, ali, fid = self.items[i]
-        audio, mel, duration = self._audio_and_mel(path)
+    def _labels(self, i):
+        _path, _text, ali, fid = self.items[i]
         starts, ends, words = [], [], []
         for item in ali:
             if item[0] == "":
@@ -145,7 +158,12 @@ class LibriSpeech(_ScpDataset):
             words.append(item[0])
             starts.append(item[1])
             ends.append(item[2])
-        return audio, mel, duration, " ".join(words), starts, ends, fid
+        return " ".join(words), starts, ends, fid
+
+    def __getitem__(self, i):
+        text, starts, ends, fid = self._labels(i)
+        audio, mel, duration = self._audio_and_mel(self.items[i][0])
+        return audio, mel, duration, text, starts, ends, fid
 
 
 class AMI(_ScpDataset):
@@ -168,10 +186,14 @@ class AMI(_ScpDataset):
                         raise KeyError("%s has no entry in %s" % (parts[0], alignment_file))
                     self.items.append((parts[1], ali[parts[0]], parts[0]))
 
-    def __getitem__(self, i):
-        path, ali, fid = self.items[i]
-        audio, mel, duration = self._audio_and_mel(path)
+    def _labels(self, i):
+        _path, ali, fid = self.items[i]
         words = [w for w, _, _ in ali if w != ""]
         starts = [float(s) for w, s, _ in ali if w != ""]
         ends = [float(e) for w, _, e in ali if w != ""]
-        return audio, mel, duration, " ".join(words), starts, ends, fid
+        return " ".join(words), starts, ends, fid
+
+    def __getitem__(self, i):
+        text, starts, ends, fid = self._labels(i)
+        audio, mel, duration = self._audio_and_mel(self.items[i][0])
+        return audio, mel, duration, text, starts, ends, fid

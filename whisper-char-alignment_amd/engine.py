@@ -55,6 +55,41 @@ def dims_for(name):
     return ModelDimensions(n_mels, 1500, d, h, l, n_vocab, 448, d, h, l)
 
 
+# openai-whisper's per-model alignment heads (`whisper._ALIGNMENT_HEADS`, applied by whisper.load_model(name) through
+# set_alignment_heads): the (layer, head) pairs of the decoder cross-attention heads highly correlated with word timing.
+# Published data of the upstream package (there it is stored as base85 + gzip boolean masks); these are the decoded
+# index lists, row-major like `model.alignment_heads.indices().T` (timing.py:155).
+ALIGNMENT_HEADS = {
+    "tiny.en": [(1, 0), (2, 0), (2, 5), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4)],
+    "tiny": [(2, 2), (3, 0), (3, 2), (3, 3), (3, 4), (3, 5)],
+    "base.en": [(3, 3), (4, 7), (5, 1), (5, 5), (5, 7)],
+    "base": [(3, 1), (4, 2), (4, 3), (4, 7), (5, 1), (5, 2), (5, 4), (5, 6)],
+    "small.en": [(6, 6), (7, 0), (7, 3), (7, 8), (8, 2), (8, 5), (8, 7), (9, 0), (9, 4), (9, 8), (9, 10), (10, 0), (10, 1), (10, 2),
+                 (10, 3), (10, 6), (10, 11), (11, 2), (11, 4)],
+    "small": [(5, 3), (5, 9), (8, 0), (8, 4), (8, 7), (8, 8), (9, 0), (9, 7), (9, 9), (10, 5)],
+    "medium.en": [(11, 4), (14, 1), (14, 12), (14, 14), (15, 4), (16, 0), (16, 4), (16, 9), (17, 12), (17, 14), (18, 7), (18, 10),
+                  (18, 15), (20, 0), (20, 3), (20, 9), (20, 14), (21, 12)],
+    "medium": [(13, 15), (15, 4), (15, 15), (16, 1), (20, 0), (23, 4)],
+    "large-v1": [(9, 19), (11, 2), (11, 4), (11, 17), (22, 7), (22, 11), (22, 17), (23, 2), (23, 15)],
+    "large-v2": [(10, 12), (13, 17), (16, 11), (16, 12), (16, 13), (17, 15), (17, 16), (18, 4), (18, 11), (18, 19), (19, 11), (21, 2),
+                 (21, 3), (22, 3), (22, 9), (22, 12), (23, 5), (23, 7), (23, 13), (25, 5), (26, 1), (26, 12), (27, 15)],
+    "large-v3": [(7, 0), (10, 17), (12, 18), (13, 12), (16, 1), (17, 14), (19, 11), (21, 4), (24, 1), (25, 6)],
+}
+ALIGNMENT_HEADS["large"] = ALIGNMENT_HEADS["large-v3"]
+
+
+def model_name_from_dims(dims):
+    """The official model name a set of dimensions identifies, or None when it is ambiguous (large-v1 / large-v2 share
+    every dimension) or not an official size."""
+    for base, (d, h, l) in _SIZES.items():
+        if (dims.n_text_state, dims.n_text_head, dims.n_text_layer) != (d, h, l) or base in ("large", "large-v1", "large-v2", "large-v3"):
+            continue
+        return base if dims.n_vocab >= 51865 else base + ".en"
+    if (dims.n_text_state, dims.n_text_head, dims.n_text_layer) == _SIZES["large"] and dims.n_mels == 128:
+        return "large-v3"
+    return None
+
+
 _registry = {}   # device index -> weakref of the most recently constructed engine
 _utility = {}    # device index -> weight-less engine created on demand for filter_attention / force_align / dtw
 
@@ -92,8 +127,10 @@ class WhisperAMD:
         _lib.check(self._lib.wca_engine_create(C.byref(cd), index, self.max_batch, C.byref(self._h)))
         self._stream_bound = None
         self._finalized = False
-        # whisper.model.Whisper default: every head of the upper half of the decoder layers (set_alignment_heads overrides)
+        # whisper.model.Whisper default: every head of the upper half of the decoder layers; whisper.load_model(name)
+        # replaces it with the model's curated heads (ALIGNMENT_HEADS) -- from_checkpoint / use_official_alignment_heads
         self.alignment_heads = [(l, h) for l in range(dims.n_text_layer // 2, dims.n_text_layer) for h in range(dims.n_text_head)]
+        self.alignment_heads_source = "default (upper half of the decoder layers)"
         filt = np.ascontiguousarray(mel_filters(dims.n_mels), dtype=np.float32)
         self._load_one("mel_filters", filt)
         if _register:
@@ -111,11 +148,29 @@ class WhisperAMD:
 
     def set_alignment_heads(self, heads):
         """heads: iterable of (layer, head) pairs used by timing.default_find_alignment."""
-        heads = [(int(l), int(h)) for l, h in heads]
+        heads = sorted({(int(l), int(h)) for l, h in heads})  # row-major like alignment_heads.indices().T (timing.py:155)
         for l, h in heads:
             if not (0 <= l < self.dims.n_text_layer and 0 <= h < self.dims.n_text_head):
                 raise ValueError("alignment head (%d, %d) out of range" % (l, h))
         self.alignment_heads = heads
+        self.alignment_heads_source = "set_alignment_heads"
+
+    def use_official_alignment_heads(self, name=None):
+        """What whisper.load_model(name) does after loading the weights: install the model's curated alignment heads.
+        `name` defaults to the official model the dimensions identify; returns the name used, or None (with a warning)
+        when there is no table for it -- default_find_alignment then averages the generic default set, which is NOT what
+        the reference's baseline uses."""
+        name = name or model_name_from_dims(self.dims)
+        heads = ALIGNMENT_HEADS.get(name)
+        if heads is not None and all(l < self.dims.n_text_layer and h < self.dims.n_text_head for l, h in heads):
+            self.set_alignment_heads(heads)
+            self.alignment_heads_source = "openai-whisper _ALIGNMENT_HEADS[%r]" % name
+            return name
+        import warnings
+        warnings.warn("no official alignment heads for %r with these dimensions: default_find_alignment will use the generic "
+                      "default (every head of the upper decoder half); pass the model name (e.g. 'large-v2') or call "
+                      "set_alignment_heads" % (name,))
+        return None
 
     def to(self, device):
         if torch.device(device) != self.device:
@@ -159,12 +214,16 @@ class WhisperAMD:
         return self
 
     @classmethod
-    def from_checkpoint(cls, path, device="cuda:0", max_batch=8):
-        """Loads an openai-format checkpoint ({'dims':..., 'model_state_dict':...}) from a LOCAL path."""
+    def from_checkpoint(cls, path, device="cuda:0", max_batch=8, name=None):
+        """Loads an openai-format checkpoint ({'dims':..., 'model_state_dict':...}) from a LOCAL path and, like
+        whisper.load_model(name), installs the official alignment heads of `name` (inferred from the dimensions when
+        they identify the model; large-v1 / large-v2 need the name)."""
         ck = torch.load(path, map_location="cpu")
         dims = ModelDimensions(**ck["dims"])
         m = cls(dims, device=device, max_batch=max_batch)
-        return m.load_state_dict(ck["model_state_dict"])
+        m.load_state_dict(ck["model_state_dict"])
+        m.use_official_alignment_heads(name)
+        return m
 
     # ---- stream handling: always run on torch's current stream so torch tensors stay ordered
     def _bind_stream(self):

@@ -81,3 +81,21 @@ def allreduce_counters(corrects, total_preds, total_gts, device=None):
     t = torch.tensor([corrects, total_preds, total_gts], dtype=torch.int64, device=dev)
     dist.all_reduce(t)
     return tuple(int(v) for v in t.tolist())
+
+
+def gather_predictions(local_predictions, dst=0):
+    """Every rank's `all_predictions` dict ({utt index: {starts, ends, texts, starts_hat, ends_hat, predwords, fids}},
+    infer_ali.py:118-119) merged on rank `dst` (returns None on the other ranks). The reference is single-process; with
+    one rank per GPU each rank only holds its shard, and eval_ali.py must see the whole corpus."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local_predictions)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bucket = [None] * world if rank == dst else None
+    dist.gather_object(dict(local_predictions), bucket, dst=dst)
+    if rank != dst:
+        return None
+    merged = {}
+    for part in bucket:
+        merged.update(part)
+    return dict(sorted(merged.items()))

@@ -160,25 +160,33 @@ def force_align(ws, tokens, tokenizer, aligned_unit_type="subword", aggregation=
     return words, start_times, end_times, matrix, scores
 
 
-def default_find_alignment(model, tokenizer, text_tokens, mel, max_frames, *, medfilt_width=7, qk_scale=1.0):
-    """openai-whisper's own aligner as restated by the reference (timing.py:116-186, `--default_whisper_timing`):
-    the cross-attention maps of `model.alignment_heads` are median filtered, softmaxed, normalised per head and
-    frame over the token axis ((w - mean) / std, population std), averaged, sliced [sot:-1] and aligned with DTW;
-    words come from tokenizer.split_to_word_tokens. Returns (words, start_times, end_times, matrix, None)."""
+def attention_weights(qk, max_frames, medfilt_width=7, qk_scale=1.0):
+    """The post-capture half of get_attentions (timing.py:63-66) on given logits: qk (L, H, n, S) f32 (the hooked
+    cross-attention logits, concatenated over layers) -> [..., :max_frames] -> median filter -> * qk_scale -> softmax."""
+    qk = _as_cuda_f32(qk)
+    eng = _engine_for(qk.device)
+    L, H, n, S = qk.shape
+    out = torch.empty(L, H, n, int(max_frames), device=qk.device, dtype=torch.float32)
+    eng._bind_stream()
+    _lib.check(eng._lib.wca_attention_weights(eng._h, C.c_void_p(qk.data_ptr()), L, H, n, S, int(max_frames), int(medfilt_width),
+                                              float(qk_scale), C.c_void_p(out.data_ptr())))
+    return out
+
+
+def _default_alignment_from_weights(eng, weights, heads, text_tokens, tokenizer):
+    """timing.py:159-186 on filtered + softmaxed maps `weights` (L, H, n, F): returns the reference's 5-tuple."""
     sot_len = len(tokenizer.sot_sequence)
-    tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]).to(model.device)
-    weights, _logits = get_attentions(mel, tokens, model, tokenizer, max_frames, medfilt_width, qk_scale)
     L, H, n, F = weights.shape
-    heads = np.asarray([l * H + h for l, h in model.alignment_heads], dtype=np.int32)
+    hd = np.asarray([l * H + h for l, h in heads], dtype=np.int32)
     N = n - sot_len - 1
-    mat = np.zeros((N, F), dtype=np.float32)
+    norm = torch.empty(len(hd), n, F, device=weights.device, dtype=torch.float32)
     ti = np.zeros(N + F, dtype=np.int32)
     tj = np.zeros(N + F, dtype=np.int32)
     plen = C.c_int32(0)
-    model._bind_stream()
-    _lib.check(model._lib.wca_default_find_alignment(model._h, C.c_void_p(weights.data_ptr()), L, H, n, F, heads.ctypes.data_as(_pi),
-                                                     len(heads), sot_len, mat.ctypes.data_as(_pf), ti.ctypes.data_as(_pi),
-                                                     tj.ctypes.data_as(_pi), C.byref(plen)))
+    eng._bind_stream()
+    _lib.check(eng._lib.wca_default_find_alignment(eng._h, C.c_void_p(weights.data_ptr()), L, H, n, F, hd.ctypes.data_as(_pi), len(hd),
+                                                   sot_len, C.c_void_p(norm.data_ptr()), None, ti.ctypes.data_as(_pi),
+                                                   tj.ctypes.data_as(_pi), C.byref(plen)))
     text_indices = ti[:plen.value].astype(np.int64)
     time_indices = tj[:plen.value].astype(np.int64)
     words, word_tokens = tokenizer.split_to_word_tokens(list(text_tokens) + [tokenizer.eot])
@@ -187,7 +195,19 @@ def default_find_alignment(model, tokenizer, text_tokens, mel, max_frames, *, me
     word_boundaries = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
     jumps = np.pad(np.diff(text_indices), (1, 0), constant_values=1).astype(bool)
     jump_times = time_indices[jumps] / TOKENS_PER_SECOND
-    return words, jump_times[word_boundaries[:-1]], jump_times[word_boundaries[1:]], torch.from_numpy(mat), None
+    return words, jump_times[word_boundaries[:-1]], jump_times[word_boundaries[1:]], norm, None
+
+
+def default_find_alignment(model, tokenizer, text_tokens, mel, max_frames, *, medfilt_width=7, qk_scale=1.0):
+    """openai-whisper's own aligner as restated by the reference (timing.py:116-186, `--default_whisper_timing`):
+    the cross-attention maps of `model.alignment_heads` (row-major (layer, head) order, like `.indices().T` of the
+    reference's sparse mask) are median filtered, softmaxed, normalised per head and frame over the token axis
+    ((w - mean) / std, population std), averaged, sliced [sot:-1] and aligned with DTW; words come from
+    tokenizer.split_to_word_tokens. Returns (words, start_times, end_times, weights, None) where `weights` are the
+    NORMALISED maps of the alignment heads, (n_heads, n, F) on the GPU, exactly the reference's 4th value."""
+    tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]).to(model.device)
+    weights, _logits = get_attentions(mel, tokens, model, tokenizer, max_frames, medfilt_width, qk_scale)
+    return _default_alignment_from_weights(model, weights.contiguous(), model.alignment_heads, text_tokens, tokenizer)
 
 
 def words_from_jump_frames(jump_frames, tokens, tokenizer, aligned_unit_type="char", want_words=True):
