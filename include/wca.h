@@ -232,6 +232,15 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
 int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int32_t* jump_frame_host,
                           int32_t* sel_idx_host);
 
+/* ---- audio I/O on the host (no GPU work, no engine): dataset.py:31,104 read the corpora through torchaudio.load; the
+ * LibriSpeech originals are FLAC. buf = the whole .flac file in memory.
+ * wca_flac_decode: out [channels][capacity_per_channel] f32 in [-1, 1) (sample / 2^(bits-1), torchaudio's
+ * normalisation); out == NULL only counts (*n_decoded = samples per channel: streams whose STREAMINFO has no total).
+ * CRC-8 / CRC-16 of every frame are verified; WCA_ERR_INVALID on a malformed / unsupported stream. */
+int wca_flac_info(const uint8_t* buf, int64_t nbytes, int32_t* sample_rate, int32_t* channels, int32_t* bits_per_sample,
+                  int64_t* total_samples);
+int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capacity_per_channel, int64_t* n_decoded);
+
 /* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
 /* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device. out_mode low byte: 0 f16 store, 1 f32 store,
  * 2 f32 accumulate; out_mode >> 8: force the tile shape (0 auto, 128, 256). */

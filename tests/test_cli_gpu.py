@@ -46,13 +46,14 @@ def test_infer_ali_and_eval_ali(corpus, capsys):
     out = root / "out"
     args = infer.parse_args(["--model", "tiny", "--random_init", "--dataset", "TIMIT", "--scp", str(scp), "--output_dir", str(out),
                              "--aggr", "topk", "--topk", "5", "--aligned_unit_type", "char", "--medfilt_width", "3", "--batch_size", "2",
-                             "--save_prediction", "--strict", "--tolerance", "0.05"])
+                             "--save_prediction", "--strict", "--tolerance", "0.05", "--teacher", "text"])
     infer.infer_dataset(args)
     js = glob.glob(str(out / "*.json"))
     assert len(js) == 1
     res = json.load(open(js[0]))
     for k in ("precision", "recall", "f1", "r_value", "model", "aggr", "topk", "aligned_unit_type", "tolerance"):
         assert k in res
+    assert res["teacher"] == "text" and "teacher_note" in res  # not the reference's protocol: said so in the results
     import joblib
     pk = glob.glob(str(out / "*-predictions.pkl"))
     preds = joblib.load(pk[0])
@@ -88,6 +89,103 @@ def test_infer_ali_teacher_asr(corpus, fake_vocab, capsys):
         assert u in preds or ("utt%d" % u) in printed
     for p in preds.values():
         assert np.all(np.diff(p["ends_hat"]) >= 0)
+
+
+def test_infer_ali_default_teacher_is_asr_and_needs_vocab(corpus):
+    """The reference always aligns the ASR hypothesis (infer_ali.py:60-68): that is the default; without a vocabulary
+    file the CLI stops with a clear message instead of silently teacher-forcing the ground truth."""
+    root, scp = corpus
+    infer = _m("infer_ali")
+    args = infer.parse_args(["--model", "tiny", "--weights", "/nonexistent/tiny.pt", "--scp", str(scp), "--output_dir", str(root / "x")])
+    assert args.teacher is None
+    with pytest.raises(SystemExit, match="--vocab"):
+        infer.infer_dataset(args)
+
+
+def test_infer_ali_default_whisper_timing_honours_strict_and_save(corpus):
+    """--default_whisper_timing (timing.py:116-186) goes through the same scoring / saving code as the main path
+    (infer_ali.py:114-132): --strict and --save_prediction are honoured, the model's official alignment heads are used."""
+    root, scp = corpus
+    infer = _m("infer_ali")
+    engine = _m("engine")
+    import joblib
+    res = {}
+    for strict in (False, True):
+        out = root / ("out_dwt%d" % strict)
+        argv = ["--model", "tiny", "--random_init", "--dataset", "TIMIT", "--scp", str(scp), "--output_dir", str(out),
+                "--aligned_unit_type", "char", "--medfilt_width", "7", "--batch_size", "2", "--save_prediction", "--tolerance", "0.05",
+                "--teacher", "text", "--default_whisper_timing"] + (["--strict"] if strict else [])
+        infer.infer_dataset(infer.parse_args(argv))
+        res[strict] = json.load(open(glob.glob(str(out / "*.json"))[0]))
+        preds = joblib.load(glob.glob(str(out / "*-predictions.pkl"))[0])
+        assert sorted(preds) == [0, 1, 2, 3, 4]
+        for p in preds.values():
+            assert len(p["ends_hat"]) == len(p["predwords"]) - 1 and np.all(np.diff(p["ends_hat"]) >= 0)
+    assert res[True]["strict"] is True and res[False]["strict"] is False
+    assert engine.ALIGNMENT_HEADS["tiny"] == [(2, 2), (3, 0), (3, 2), (3, 3), (3, 4), (3, 5)]
+    assert len(engine.ALIGNMENT_HEADS["medium"]) == 6 and engine.model_name_from_dims(engine.dims_for("medium")) == "medium"
+    assert engine.model_name_from_dims(engine.dims_for("large-v2")) is None and engine.model_name_from_dims(engine.dims_for("large-v3")) == "large-v3"
+
+
+def test_infer_ali_pipeline_throughput(wca, tmp_path):
+    """The CLI gets the engine's throughput: a 384-utterance TIMIT-shaped corpus (10 s SPHERE files, .wrd ground truth,
+    64-char transcripts) through infer_ali --teacher text at whisper-medium dimensions, batch 64, must run within 20 %
+    of the enqueue / fetch loop bench.py times on resident inputs at the same batch size (reader threads, pinned
+    staging and the two-deep enqueue / fetch hide the host I/O)."""
+    import time
+    infer, syn, tk, rt, tm = _m("infer_ali"), _m("synthetic"), _m("tokenizer"), _m("retokenize"), _m("timing")
+    B, n_utt = 64, 384
+    lines = []
+    for u in range(n_utt):
+        x = (syn.synth_audio(5000 + u, 160000) * 32767.0).astype("<i2")
+        head = ("NIST_1A\n   1024\nsample_count -i %d\nsample_rate -i 16000\nchannel_count -i 1\nsample_n_bytes -i 2\n"
+                "sample_byte_format -s2 01\nsample_coding -s3 pcm\nend_head\n" % len(x)).encode()
+        wav = tmp_path / ("s%d.wav" % u)
+        wav.write_bytes(head + b" " * (1024 - len(head)) + x.tobytes())
+        words = syn.synth_text(5000 + u, 64).split()
+        step = len(x) // (len(words) + 1)
+        (tmp_path / ("s%d.wrd" % u)).write_text("".join("%d %d %s\n" % (i * step, (i + 1) * step, w) for i, w in enumerate(words)))
+        lines.append("s%d %s\n" % (u, wav))
+    scp = tmp_path / "big.scp"
+    scp.write_text("".join(lines))
+    dims = wca.dims_for("medium")
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(syn.random_state_dict(dims, seed=0))
+    tok = tk.get_tokenizer(True, language="English")
+    # reference rate: bench.py's loop (inputs resident in HBM, two batches in flight, host tail overlapped)
+    opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
+    pcm = torch.from_numpy(np.stack([syn.synth_audio(5000 + u, 160000) for u in range(B)])).cuda()
+    tts = [rt.encode(syn.synth_text(5000 + u, 64), tok, "char") for u in range(B)]
+    toks = torch.tensor([[*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot] for tt in tts], dtype=torch.int64).cuda()
+
+    def loop(steps):
+        t0 = time.time()
+        for i in range(steps):
+            model.align_batch(pcm, [160000] * B, toks, [69] * B, [500] * B, opts, enqueue_only=True)
+            if i > 0:
+                jump, _ = model.fetch(B, 69, opts)
+                for j in range(B):
+                    tm.words_from_jump_frames(jump[j], tts[j], tok, "char")
+        model.fetch(B, 69, opts)
+        torch.cuda.synchronize()
+        return steps * B / (time.time() - t0)
+
+    loop(2)
+    rate_bench = loop(6)
+    argv = ["--model", "medium", "--random_init", "--dataset", "TIMIT", "--scp", str(scp), "--aggr", "topk", "--topk", "10",
+            "--aligned_unit_type", "char", "--medfilt_width", "3", "--batch_size", str(B), "--teacher", "text", "--tolerance", "0.05",
+            "--readers", "8"]
+    infer.infer_dataset(infer.parse_args(argv + ["--output_dir", str(tmp_path / "warm")]), model=model)   # page cache + buffers warm
+    r = infer.infer_dataset(infer.parse_args(argv + ["--output_dir", str(tmp_path / "timed")]), model=model)
+    rate_cli = r["utterances"] / r["seconds"]
+    line = "infer_ali CLI: %d utterances in %.2f s = %.0f utt/s; enqueue/fetch loop on resident inputs %.0f utt/s (ratio %.2f)" % (
+        r["utterances"], r["seconds"], rate_cli, rate_bench, rate_cli / rate_bench)
+    print(line)
+    if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")):
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r02_cli_throughput.txt"), "a") as f:
+            f.write(line + "\n")
+    assert r["utterances"] == n_utt
+    assert rate_cli >= 0.8 * rate_bench, line
+    del model
 
 
 def test_probe_heads_matches_per_head_force_align(wca):

@@ -243,3 +243,97 @@ def test_ami_dataset_wrapper(tmp_path):
     scp.write_text("missing_segment %s\n" % wav)
     with pytest.raises(KeyError):
         ds.AMI(str(scp), compute_mel=False, alignment_file=str(pkl))
+
+
+# ----------------------------------------------------------------------------- FLAC (LibriSpeech originals, dataset.py:104)
+def test_flac_rfc9639_example_known_answer():
+    """The 57-byte example stream of RFC 9639 (appendix D.1: one 1-sample stereo frame, 16 bit, 44.1 kHz, two VERBATIM
+    subframes with 2 and 4 wasted bits). Hand decode: subframe 1 = 0b01100011111101 << 2 = 25588, subframe 2 =
+    0b001010001011 << 4 = 10416; header CRC-8 0xbf and frame CRC-16 0xaa9a are verified by the decoder."""
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    b = bytes.fromhex("664c6143800000221000100000000f00000f0ac442f0000000013e84b41807dc690307586a3dad1a2e0ffff869180000bf0358fd03128baa9a")
+    y, sr = audio._read_flac(b)
+    assert sr == 44100 and y.shape == (2, 1)
+    assert np.array_equal(np.round(y[:, 0] * 32768).astype(int), [25588, 10416])
+    bad = bytearray(b)
+    bad[-4] ^= 0x10  # corrupt one payload bit: the frame CRC-16 must catch it
+    with pytest.raises(ValueError):
+        audio._read_flac(bytes(bad))
+
+
+def test_flac_decoder_round_trip(tmp_path):
+    """Every stream shape the decoder claims, encoded by the in-test encoder (tests/flac_fixture.py) and decoded bit-exactly:
+    LPC / FIXED 0-4 / VERBATIM / CONSTANT subframes, Rice and Rice2 with escaped partitions, partition orders 0-3, wasted
+    bits, the four stereo modes, 8 / 16 / 24 bit, a short last frame, STREAMINFO without a sample count."""
+    import flac_fixture as ff
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    rng = np.random.default_rng(0)
+    t = np.arange(9000)
+    speechy = (6000 * np.sin(t * 0.03) * np.sin(t * 0.0007) + 200 * rng.standard_normal(len(t))).astype(np.int64)
+    cases = []
+    for kinds in [("lpc",), (("fixed", 0), ("fixed", 1), ("fixed", 2), ("fixed", 3), ("fixed", 4)), ("verbatim",), ("lpc", ("fixed", 2), "verbatim")]:
+        for rice2 in (False, True):
+            for esc in (False, True):
+                for porder in (0, 3):
+                    cases.append(dict(pcm=speechy, kinds=kinds, rice2=rice2, escape_first=esc, porder=porder, blocksize=1024))
+    cases.append(dict(pcm=np.full(5000, -1234), kinds=("constant",), blocksize=4096))
+    cases.append(dict(pcm=speechy * 8, kinds=("lpc",), blocksize=1152))                       # 3 wasted bits
+    cases.append(dict(pcm=speechy, kinds=("lpc",), blocksize=4096, with_total=False))          # unknown length: counted first
+    cases.append(dict(pcm=speechy // 64, kinds=(("fixed", 2),), bps=8, blocksize=576))
+    cases.append(dict(pcm=speechy * 200 + 7, kinds=("lpc", ("fixed", 4)), bps=24, blocksize=2048, rice2=True))
+    right = np.roll(speechy, 5) + (rng.integers(-50, 50, len(speechy)))
+    for mode in ("independent", "left_side", "right_side", "mid_side"):
+        cases.append(dict(pcm=np.stack([speechy, right]), kinds=("lpc", ("fixed", 1)), stereo=mode, blocksize=1024))
+    for c in cases:
+        pcm = np.asarray(c.pop("pcm"), dtype=np.int64)
+        bps = c.get("bps", 16)
+        y, sr = audio._read_flac(ff.encode(pcm, **c))
+        assert sr == 16000
+        got = np.round(np.asarray(y, dtype=np.float64) * (1 << (bps - 1))).astype(np.int64)
+        assert got.shape == pcm.shape and np.array_equal(got, pcm), c
+    # through the file loader (container sniffing) and a truncated file
+    p = tmp_path / "x.flac"
+    p.write_bytes(ff.encode(speechy))
+    y, sr = audio.load_audio(str(p))
+    assert sr == 16000 and np.array_equal(np.round(y * 32768).astype(np.int64), speechy)
+    with pytest.raises(ValueError):
+        audio._read_flac(ff.encode(speechy)[:3000])
+
+
+def test_librispeech_dataset_flac_tree(tmp_path):
+    """dataset.LibriSpeech (dataset.py:67-122) on a fake corpus tree: `<root>/<split>/<spk>/<chap>/<fid>.flac`,
+    `*.trans.txt` transcripts, `ls_alignment_<split>.txt` word alignments (python-literal lists, empty words dropped),
+    scp lines `<fid> <path>`; FLAC decoded in-tree; audio longer than 30 s trimmed by pad_or_trim, duration kept."""
+    import flac_fixture as ff
+    ds = importlib.import_module("whisper-char-alignment_amd.dataset")
+    rng = np.random.default_rng(3)
+    root = tmp_path / "LibriSpeech"
+    split = "test-clean"
+    scp_lines, ali_lines = [], []
+    lens = {"1089-134686-0000": 52000, "1089-134686-0001": 33000, "121-127105-0003": 16000 * 31}
+    for fid, n in lens.items():
+        spk, chap, _ = fid.split("-")
+        d = root / split / spk / chap
+        d.mkdir(parents=True, exist_ok=True)
+        pcm = (3000 * np.sin(np.arange(n) * 0.01) + 100 * rng.standard_normal(n)).astype(np.int64)
+        (d / (fid + ".flac")).write_bytes(ff.encode(pcm, blocksize=4096, kinds=("lpc",)))
+        with open(d / ("%s-%s.trans.txt" % (spk, chap)), "a") as f:
+            f.write("%s HELLO BIG WORLD\n" % fid)
+        ali_lines.append("%s [('', 0.0, 0.2), ('HELLO', 0.2, 0.7), ('BIG', 0.7, 1.0), ('', 1.0, 1.1), ('WORLD', 1.1, 1.9)]\n" % fid)
+        scp_lines.append("%s %s\n" % (fid, d / (fid + ".flac")))
+    scp = tmp_path / "test-clean.wav.scp"
+    scp.write_text("".join(scp_lines))
+    ali = tmp_path / ("ls_alignment_%s.txt" % split)
+    ali.write_text("".join(ali_lines))
+    data = ds.LibriSpeech(str(scp), n_mels=80, device="cpu", model=None, compute_mel=False, alignment_file=str(ali))
+    assert len(data) == 3
+    for i, (fid, n) in enumerate(lens.items()):
+        audio, mel, duration, text, starts, ends, got_fid = data[i]
+        assert got_fid == fid and mel is None and duration == n and tuple(audio.shape) == (480000,)
+        assert text == "HELLO BIG WORLD" and starts == [0.2, 0.7, 1.1] and ends == [0.7, 1.0, 1.9]
+        pcm, dur, text2, st2, en2, fid2 = data.read(i)   # the reader-pool entry: un-padded PCM, trimmed to 30 s
+        assert dur == n and len(pcm) == min(n, 480000) and (text2, st2, en2, fid2) == (text, starts, ends, fid)
+        assert np.array_equal(pcm, audio.numpy()[:len(pcm)])
+    assert data.duration_hint(2) > data.duration_hint(1)
+    audio, mel, duration, text, starts, ends, fid = ds.Collate()([data[0]])
+    assert fid == "1089-134686-0000" and duration == 52000

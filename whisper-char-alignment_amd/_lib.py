@@ -61,6 +61,8 @@ SIGNATURES = {
     "wca_force_align": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(AlignOpts), _pf, _pi32, _pi32, _pi32, _pi32, _pf]),
     "wca_default_find_alignment": (_i, [_vp, _vp, _i, _i, _i, _i, _pi32, _i, _i, _vp, _pf, _pi32, _pi32, _pi32]),
     "wca_attention_weights": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "wca_flac_info": (_i, [_vp, _i64, _pi32, _pi32, _pi32, C.POINTER(_i64)]),
+    "wca_flac_decode": (_i, [_vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "wca_dtw": (_i, [_vp, _pf, _i, _i, _pi32, _pi32, _pi32]),
     "wca_dtw_batch_dev": (_i, [_vp, _vp, _i, _i, _i, _pi32]),
     "wca_probe_heads": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _pf, _pi32]),

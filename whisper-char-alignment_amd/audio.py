@@ -156,13 +156,40 @@ def _read_riff(buf):
     return pcm, sr
 
 
+def _read_flac(buf):
+    """FLAC (LibriSpeech originals) through libwca.so's host-side decoder (csrc/flac.cpp; ctypes releases the GIL, so
+    reader threads decode in parallel). Returns (f32 [n] or [channels, n] in [-1, 1), sample_rate)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    buf = bytes(buf)
+    src = C.cast(C.c_char_p(buf), C.c_void_p)
+    sr, ch, bits, total = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    if lib.wca_flac_info(src, len(buf), C.byref(sr), C.byref(ch), C.byref(bits), C.byref(total)) != 0:
+        raise ValueError("not a FLAC stream")
+    n = C.c_int64(0)
+    n_total = total.value
+    if n_total <= 0:  # STREAMINFO without a sample count: count first
+        if lib.wca_flac_decode(src, len(buf), None, 0, C.byref(n)) != 0:
+            raise ValueError("corrupt or unsupported FLAC stream")
+        n_total = n.value
+    out = np.empty((ch.value, max(n_total, 1)), dtype=np.float32)
+    rc = lib.wca_flac_decode(src, len(buf), out.ctypes.data_as(C.c_void_p), out.shape[1], C.byref(n))
+    if rc != 0:
+        raise ValueError("corrupt or unsupported FLAC stream (wca_flac_decode returned %d)" % rc)
+    out = out[:, :n.value]
+    return (out[0] if ch.value == 1 else out), sr.value
+
+
 def load_audio(path):
     """torchaudio.load stand-in for the formats the reference corpora use: returns (f32 array in
-    [-1, 1) shaped [n] (mono) or [channels, n], sample_rate). TIMIT '.wav' files are NIST SPHERE."""
+    [-1, 1) shaped [n] (mono) or [channels, n], sample_rate). TIMIT '.wav' files are NIST SPHERE, LibriSpeech is FLAC."""
     with open(path, "rb") as f:
         buf = f.read()
     if buf[:7] == b"NIST_1A":
         return _read_sphere(buf)
     if buf[:4] == b"RIFF":
         return _read_riff(buf)
-    raise ValueError("%s: unknown audio container (SPHERE and RIFF/WAVE supported)" % path)
+    if buf[:4] == b"fLaC":
+        return _read_flac(buf)
+    raise ValueError("%s: unknown audio container (SPHERE, RIFF/WAVE and FLAC supported)" % path)

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwca.so")
-SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "attention.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip", "flac.cpp"]
 HEADERS = ["kernels.h", "wca_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "wca.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (the softmax / epilogue VALU code reads them
 # directly; the AGPR form costs a v_accvgpr_read/write pair per element in the attention loop)
@@ -43,13 +43,16 @@ def build_lib(force=False, verbose=True):
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + hdrs):
             jobs.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
+        if s.endswith(".cpp"):  # host-only source (audio file decoding): plain C++, no device code
+            cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c", s, "-o", o]
+        else:
+            cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (s, r.stdout, r.stderr))
@@ -59,7 +62,7 @@ def build_lib(force=False, verbose=True):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(cc, jobs))
-    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    objs = [os.path.join(OBJ, os.path.splitext(s)[0] + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

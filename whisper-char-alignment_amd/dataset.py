@@ -4,8 +4,8 @@ by a Kaldi-style `.scp` list (`<fid> <path>` per line, README.md:55-62), plus Co
 
 Differences from the reference, all on the I/O side (the per-item tuple is unchanged):
   * audio is read lazily (the reference's TIMIT loads the whole corpus in __init__, dataset.py:26-36);
-  * no torchaudio: NIST SPHERE / RIFF WAV are parsed by audio.load_audio (TIMIT '.wav' files are SPHERE);
-    FLAC (LibriSpeech) needs the optional `soundfile` package and fails with a clear message without it;
+  * no torchaudio: NIST SPHERE / RIFF WAV are parsed by audio.load_audio (TIMIT '.wav' files are SPHERE) and FLAC
+    (LibriSpeech) by the in-tree host decoder csrc/flac.cpp (wca_flac_decode);
   * `ls_alignment_{split}.txt` lines are parsed with ast.literal_eval instead of eval (dataset.py:87);
   * the log-mel is computed on the GPU by the engine (csrc/logmel.hip) instead of torch.stft on the host;
     `__getitem__` returns mel=None when constructed with compute_mel=False (the fused batch path takes PCM).
@@ -22,16 +22,7 @@ from . import audio as _audio
 
 
 def _load_mono(path):
-    try:
-        pcm, sr = _audio.load_audio(path)
-    except ValueError:
-        try:
-            import soundfile as sf
-        except ImportError:
-            raise RuntimeError("%s is neither NIST SPHERE nor RIFF/WAVE and the optional `soundfile` package (needed for "
-                               "FLAC) is not installed; convert the corpus to 16 kHz WAV" % path)
-        pcm, sr = sf.read(path, dtype="float32", always_2d=False)
-        pcm = pcm.T
+    pcm, sr = _audio.load_audio(path)  # NIST SPHERE / RIFF WAVE / FLAC, all decoded in-tree
     pcm = np.asarray(pcm, dtype=np.float32)
     if pcm.ndim > 1:
         pcm = pcm.reshape(-1) if pcm.shape[0] == 1 else pcm[0]

@@ -121,7 +121,8 @@ class PinnedStager:
         return dev, [len(b["pcm"]) for b in batch]
 
 
-def infer_dataset(args):
+def infer_dataset(args, model=None):
+    """`model`: an already constructed WhisperAMD engine (tests / long-lived services); default: load_model(args)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,7 +146,10 @@ def infer_dataset(args):
                   "(infer_ali.py:60-68), so these scores are optimistic w.r.t. the reference's protocol", file=sys.stderr)
         if args.plot:
             print("WARNING: --plot is not supported by this engine (no matplotlib side-car); ignored", file=sys.stderr)
-    model = load_model(args, device)
+    if model is None:
+        model = load_model(args, device)
+    if args.batch_size > model.max_batch:
+        raise SystemExit("--batch_size %d exceeds the engine's max_batch %d" % (args.batch_size, model.max_batch))
     if args.n_mels != model.dims.n_mels:
         raise SystemExit("--n_mels %d does not match the checkpoint (%d); large-v3 needs --n_mels 128" % (args.n_mels, model.dims.n_mels))
     tokenizer = get_tokenizer(model.is_multilingual, language="English", vocab_path=args.vocab)
