@@ -7,18 +7,24 @@
 One "step" = one pass of the whole per-utterance pipeline (log-mel -> Whisper encoder/decoder with every
 cross-attention head captured -> median filter -> softmax -> head scores / top-k -> aggregation -> DTW ->
 word times) over one micro-batch of synthetic utterances per GPU: whisper-medium dimensions with seeded
-random weights (no checkpoint exists offline), 10 s of 16 kHz audio, 64-character teacher text, char
-alignment, --aggr topk --topk 10 --medfilt_width 3 (BASELINE.json configs[1], TIMIT-shaped).
-Utterances shard across ranks with no data-path collective; one RCCL all-gather collates the results.
+random weights (no checkpoint exists offline; the cross-attention q/k weights are widened so the maps are PEAKY and
+the parity leg is sensitive to operand rounding), 10 s of 16 kHz audio, 64-character teacher text, char alignment,
+--aggr topk --topk 10 --medfilt_width 3 (BASELINE.json configs[1], TIMIT-shaped). 1 024 distinct utterances per GPU
+are resident in HBM and cycled. Utterances shard across ranks with no data-path collective; the results are collated
+by the PRODUCT's collation (shard.allgather_results: packed records, size gather + one all-gather; 3-counter
+all-reduce) inside the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) including `roofline` for the dominant
-kernel (encoder MLP fc1 GEMM) measured live with HIP events, and `cpu_baseline` (the oracle's PyTorch-CPU
-restatement of the same pipeline, timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  * `roofline`: the encoder kernel with the LARGEST total time in the step (HIP-event pairs around every launch of every
+    encoder kernel site, recorded live on the stream the kernels run on), `kernels`: the same figures for every site;
+  * `cpu_baseline`: the oracle's PyTorch-CPU restatement of the same pipeline timed on this box's host cores on a bounded
+    sample, and the parity of the GPU path against it at exactly the timed configuration.
 """
 import argparse
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,26 +36,38 @@ sys.path.insert(0, ROOT)
 
 METRIC = "utterances/sec (whisper-medium, 10s audio, char align) at 1/2/4/8 MI355X"
 MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f16
+HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+SITE_SYMBOL = {
+    "qkv": "gemm256p_f16_kernel<0, false, 1, false> (encoder QKV projection, N=3d K=d)",
+    "attention": "attn_kernel<false, false, false> (encoder self-attention 1500x1500, head_dim 64)",
+    "out_proj": "gemm256p_f16_kernel<2, false, 1, false> (encoder attention out-projection + residual, N=d K=d)",
+    "fc1": "gemm256p_f16_kernel<0, true, 1, false> (encoder MLP fc1 + GELU, N=4d K=d)",
+    "fc2": "gemm256p_f16_kernel<2, false, 4, false> (encoder MLP fc2 + residual, N=d K=4d)",
+    "ln1": "layernorm_f16 (attn_ln)",
+    "ln2": "layernorm_f16 (mlp_ln)",
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed micro-batches per GPU (the two-deep pipeline drains once inside the timed region)")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed micro-batches per GPU (>= 20 s at the default batch)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU per step")
+    ap.add_argument("--distinct-batches", type=int, default=16, help="distinct micro-batches resident per GPU (16 x 64 = 1 024 utterances)")
     ap.add_argument("--model", type=str, default="medium")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--chars", type=int, default=64)
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-utts", type=int, default=4, help="utterances timed by the CPU baseline (after 1 warm-up): ~10-12 s of CPU work")
+    ap.add_argument("--cpu-utts", type=int, default=32, help="utterances timed by the CPU baseline (after 1 warm-up)")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
+    ap.add_argument("--no-overlap", action="store_true", help="phase 2 on the same stream as phase 1 (clean per-kernel rocprofv3 averages)")
     return ap.parse_args()
 
 
-def build_inputs(wca_pkg, syn, tok_mod, retok, args, n_batches, rank, world, device):
+def build_inputs(syn, tok_mod, retok, args, n_batches, rank, world, device):
     tok = tok_mod.get_tokenizer(True, language="English")
     n_samples = int(args.seconds * 16000)
     batches = []
@@ -70,14 +88,25 @@ def build_inputs(wca_pkg, syn, tok_mod, retok, args, n_batches, rank, world, dev
         for j, f in enumerate(toks):
             tarr[j, :len(f)] = f
         batches.append(dict(pcm=torch.from_numpy(pcm).to(device), tokens=torch.from_numpy(tarr).to(device), n_tok=ntoks,
-                            n_samples=[n_samples] * args.batch, max_frames=[n_samples // 320] * args.batch, texts=texts))
+                            n_samples=[n_samples] * args.batch, max_frames=[n_samples // 320] * args.batch, texts=texts, n_max=n_max))
     return tok, batches
 
 
-def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod, oracle_times):
-    """Oracle (CPU restatement of the reference pipeline, kind 'port') on a bounded sample."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
+    """Oracle (CPU restatement of the reference pipeline, kind 'port') on a bounded sample, every host core."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
-    cores = min(os.cpu_count() or 1, 16)
+    cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
     tok = tokenizer_ref.CharTokenizer()
     ref = whisper_ref.WhisperRef(sd, dims)
@@ -99,60 +128,71 @@ def cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod, oracle_times):
         if u > 0:
             times.append(dt)
     per = float(np.mean(times))
-    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "kind": "port",
-            "sample": "%d utterances (after 1 warm-up) of the same synthetic workload, batch 1 serial like infer_ali.py, "
-                      "PyTorch-CPU fp32 forward + oracle post-processing, %.2f s/utt" % (len(times), per)}
+    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+            "sample": "%d utterances (after 1 warm-up) of the same synthetic workload, batch 1 serial like infer_ali.py:48,57, "
+                      "PyTorch-CPU fp32 forward (torch.set_num_threads(%d)) + oracle post-processing, %.2f s/utt" % (len(times), cores, per)}
 
 
 def parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device):
-    """The utterances the CPU baseline just aligned, through the GPU path inside a FULL bench-sized micro-batch (so the
+    """The utterances the CPU baseline just aligned, through the GPU path inside FULL bench-sized micro-batches (so the
     persistent GEMMs, the batched attention grid and the batched DTW run at exactly the timed configuration); compares
     word start / end times with the oracle's. Not part of the timed region."""
     n_samples = int(args.seconds * 16000)
-    ids = [u for u, _t, _s, _e in oracle_times]
-    ids = (ids * ((args.batch + len(ids) - 1) // len(ids)))[:args.batch]  # fill the batch by repetition
-    pcm = np.stack([syn.synth_audio(u, n_samples) for u in ids])
-    texts = {u: t for u, t, _s, _e in oracle_times}
-    rows, tts = [], []
-    for u in ids:
-        tt = retok.encode(texts[u], tok, "char")
-        tts.append(tt)
-        rows.append([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
-    n_max = max(len(r) for r in rows)
-    toks = np.full((len(rows), n_max), tok.eot, dtype=np.int64)
-    for j, r in enumerate(rows):
-        toks[j, :len(r)] = r
-    jump, _ = model.align_batch(torch.from_numpy(pcm).to(device), [n_samples] * len(ids), torch.from_numpy(toks).to(device),
-                                [len(r) for r in rows], [n_samples // 320] * len(ids), opts)
     total = within = identical = 0
-    for j, u in enumerate(ids[:len(oracle_times)]):
-        _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
-        _u, _t, rst, ren = oracle_times[j]
-        for a, b in ((np.asarray(st), rst), (np.asarray(en), ren)):
-            if len(a) != len(b):
-                return {"utterances": len(oracle_times), "error": "word count differs"}
-            total += len(a)
-            within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
-            identical += int(np.sum(a == b))
-    # batch invariance: the repeated copies of an utterance inside the batch must give the same frames
-    invariant = all(np.array_equal(jump[j][:len(rows[j])], jump[j % len(oracle_times)][:len(rows[j])]) for j in range(len(ids)))
+    invariant = True
+    for lo in range(0, len(oracle_times), args.batch):
+        chunk = oracle_times[lo:lo + args.batch]
+        ids = [u for u, _t, _s, _e in chunk]
+        ids = (ids * ((args.batch + len(ids) - 1) // len(ids)))[:args.batch]  # fill the batch by repetition
+        pcm = np.stack([syn.synth_audio(u, n_samples) for u in ids])
+        texts = {u: t for u, t, _s, _e in chunk}
+        rows, tts = [], []
+        for u in ids:
+            tt = retok.encode(texts[u], tok, "char")
+            tts.append(tt)
+            rows.append([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
+        n_max = max(len(r) for r in rows)
+        toks = np.full((len(rows), n_max), tok.eot, dtype=np.int64)
+        for j, r in enumerate(rows):
+            toks[j, :len(r)] = r
+        jump, _ = model.align_batch(torch.from_numpy(pcm).to(device), [n_samples] * len(ids), torch.from_numpy(toks).to(device),
+                                    [len(r) for r in rows], [n_samples // 320] * len(ids), opts)
+        for j in range(len(chunk)):
+            _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
+            _u, _t, rst, ren = chunk[j]
+            for a, b in ((np.asarray(st), rst), (np.asarray(en), ren)):
+                if len(a) != len(b):
+                    return {"utterances": len(oracle_times), "error": "word count differs"}
+                total += len(a)
+                within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
+                identical += int(np.sum(a == b))
+        # batch invariance: the repeated copies of an utterance inside the batch must give the same frames
+        invariant = invariant and all(np.array_equal(jump[j][:len(rows[j])], jump[j % len(chunk)][:len(rows[j])]) for j in range(len(ids)))
     return {"utterances": len(oracle_times), "word_boundaries": total, "within_one_frame": within, "identical": identical,
-            "batch_invariant": bool(invariant), "tolerance": "one 20 ms encoder frame (north_star)"}
+            "batch_invariant": bool(invariant), "weights": "peaky (cross_qk_std=0.08)", "tolerance": "one 20 ms encoder frame (north_star)"}
 
 
-def measured_traffic(args, dims):
-    """L2<->fabric bytes per launch of the dominant kernel from the rocprofv3 PMC passes recorded under profiles/
-    (FETCH_SIZE doubled as the gfx950 note in MI355X_MICROARCH.md prescribes, + WRITE_SIZE); only quoted when this
-    run uses the configuration those passes were collected on, else null."""
-    path = os.path.join(ROOT, "profiles", "r01_dominant_kernel_traffic.json")
+def measured_traffic(args, dims, site):
+    """HBM-side bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes recorded under
+    profiles/ (tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
+    Quoted only when that file was collected on this configuration and this kernel; carries its provenance."""
+    path = os.path.join(ROOT, "profiles", "r02_dominant_kernel_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
-        if rec["M"] == args.batch * 1500 and rec["N"] == 4 * dims.n_audio_state and rec["K"] == dims.n_audio_state:
-            return rec["traffic_bytes_per_launch"]
+        if rec.get("site") == site and rec["batch"] == args.batch and rec["model"] == args.model:
+            return rec["traffic_bytes_per_launch"], {"file": "profiles/r02_dominant_kernel_traffic.json", "commit": rec.get("commit"),
+                                                     "collected": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not this run"}
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except (OSError, subprocess.SubprocessError):
+        return None
 
 
 def main():
@@ -182,15 +222,17 @@ def main():
     retok = importlib.import_module("whisper-char-alignment_amd.retokenize")
     timing = importlib.import_module("whisper-char-alignment_amd.timing")
     audio_mod = importlib.import_module("whisper-char-alignment_amd.audio")
+    shard = importlib.import_module("whisper-char-alignment_amd.shard")
 
     dims = wca.dims_for(args.model)
-    sd = syn.random_state_dict(dims, seed=0)
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
     model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch)
     model.load_state_dict(sd)
-    tok, batches = build_inputs(wca, syn, tok_mod, retok, args, 2, rank, world, device)
+    if args.no_overlap:
+        model.set_overlap(False)
+    tok, batches = build_inputs(syn, tok_mod, retok, args, max(2, args.distinct_batches), rank, world, device)
     opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width,
                            qk_scale=1.0)
-    n_max = batches[0]["tokens"].shape[1]
 
     def enqueue(i):
         b = batches[i % len(batches)]
@@ -198,25 +240,21 @@ def main():
 
     def finish(i, collect=None):
         b = batches[i % len(batches)]
-        jump, _sel = model.fetch(args.batch, n_max, opts)
+        jump, _sel = model.fetch(args.batch, b["n_max"], opts)
         # host tail: word-boundary merge + jump frames -> word start/end times (timing.py:105-113)
         for j in range(args.batch):
-            _words, _st, _en = timing.words_from_jump_frames(jump[j], b["texts"][j], tok, "char")
-        if collect is not None:
-            collect.append(jump)
-
-    def step(i, collect=None):
-        enqueue(i)
-        finish(i, collect)
+            _words, st, en = timing.words_from_jump_frames(jump[j], b["texts"][j], tok, "char", want_words=False)
+            if collect is not None:
+                collect[(i * args.batch + j) * world + rank] = (st, en)
 
     for i in range(args.warmup):
-        step(i)
+        enqueue(i)
+        finish(i)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     model.set_profiling(True)
-    stage_acc = np.zeros(8)
-    results = []
+    results = {}
     t0 = time.perf_counter()
     # software pipeline of depth 2: the host tail of step i-1 runs while the GPU executes step i
     for i in range(args.steps):
@@ -224,23 +262,21 @@ def main():
         if i > 0:
             finish(i - 1, results)
     finish(args.steps - 1, results)
-    # HIP-event pairs around every launch of the dominant kernel were recorded on the engine stream during the
-    # last timed step (they are re-recorded by each enqueue): 24 launches of the encoder fc1 GEMM
-    dom_n, dom_ms, dom_flops = model.dominant_kernel_ms()
-    if args.stages:
-        stage_acc += np.array(model.last_stage_ms())
-    # collate: one all-gather of the packed per-utterance jump frames (the only collective on the path)
+    # collate exactly like infer_ali.py does: packed (index, n, starts, ends) records through one size gather + one
+    # all-gather, and the 3-counter all-reduce (the only collectives on the path; no-ops for one rank)
     coll_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
-    packed = torch.from_numpy(np.stack(results).astype(np.int32)).to(coll_dev)
-    if dist is not None:
-        gathered = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=coll_dev)
-        dist.all_gather_into_tensor(gathered, packed)
-        _ = gathered.cpu()
+    merged = shard.allgather_results(results, device=coll_dev)
+    counters = shard.allreduce_counters(len(results), len(results), len(results), device=coll_dev)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    # HIP-event pairs around every launch of every encoder kernel were recorded on the engine stream during the
+    # last timed step (they are re-recorded by each enqueue)
+    sites = {s: model.kernel_ms(s) for s in ("qkv", "attention", "out_proj", "fc1", "fc2", "ln1", "ln2")}
+    stage_ms = model.last_stage_ms() if args.stages else None
     model.set_profiling(False)
+    assert len(merged) == world * args.steps * args.batch and counters[0] == len(merged)
     if dist is not None:
         tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -248,28 +284,43 @@ def main():
 
     if rank == 0:
         total_utts = world * args.batch * args.steps
-        avg_ms = dom_ms / max(dom_n, 1)
-        achieved = dom_flops / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        kernels = {}
+        for s, (n, ms, fl, by) in sites.items():
+            avg = ms / max(n, 1)
+            mfma = s not in ("ln1", "ln2")
+            ach = (fl if mfma else by) / (avg * 1e-3) / (1e12 if mfma else 1e9) if avg > 0 else 0.0
+            kernels[s] = {"symbol": SITE_SYMBOL[s], "launches": n, "avg_launch_ms": avg, "total_ms": ms, "bound": "mfma" if mfma else "hbm",
+                          "achieved": ach, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / (MFMA_F16_DENSE_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)}
+        dom = max(kernels, key=lambda s: kernels[s]["total_ms"])
+        traffic, traffic_src = measured_traffic(args, dims, dom)
+        d = dims.n_audio_state
         out = {
             "metric": METRIC, "value": total_utts / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "configs[1] shape (TIMIT-like): whisper-%s dims, seeded random weights, %.0f s @ 16 kHz gated noise, "
-                                   "%d-char teacher text, char align, aggr=topk topk=%d medfilt_width=%d" %
-                                   (args.model, args.seconds, args.chars, args.topk, args.medfilt_width),
-                       "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world},
-            "roofline": {"bound": "mfma", "kernel": "gemm256p_f16_kernel<0, true, 1, false> (encoder MLP fc1, M=%d N=%d K=%d)" %
-                                                     (args.batch * 1500, 4 * dims.n_audio_state, dims.n_audio_state),
-                         "achieved": achieved, "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / MFMA_F16_DENSE_PEAK_TFLOPS, "traffic": measured_traffic(args, dims),
-                         "avg_launch_ms": avg_ms, "launches_timed": dom_n},
+            "config": {"workload": "configs[1] shape (TIMIT-like): whisper-%s dims, seeded random weights (peaky cross-attention), %.0f s @ 16 kHz "
+                                   "gated noise, %d-char teacher text, char align, aggr=topk topk=%d medfilt_width=%d; %d distinct utterances per GPU"
+                                   % (args.model, args.seconds, args.chars, args.topk, args.medfilt_width, len(batches) * args.batch),
+                       "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world,
+                       "streams": "one (no overlap)" if args.no_overlap else "phase 1 / phase 2 overlapped on two streams",
+                       "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region",
+                       "pipeline_tflops": total_utts * 1.356 / elapsed, "commit": git_head()},
+            "roofline": {"bound": "mfma", "kernel": "%s, M=%d d=%d" % (SITE_SYMBOL[dom], args.batch * 1500, d),
+                         "selected_as": "largest total time of the encoder kernel sites in the last timed step",
+                         "achieved": kernels[dom]["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": sites[dom][3], "algorithmic_flops": sites[dom][2],
+                         "avg_launch_ms": kernels[dom]["avg_launch_ms"], "launches_timed": kernels[dom]["launches"]},
+            "kernels": kernels,
         }
-        if args.stages:
+        if stage_ms is not None:
             names = ["logmel", "encoder", "cross_kv", "decoder", "head_stats", "topk_aggregate", "dtw", "total"]
-            print("stage ms/step (last step): " + ", ".join("%s=%.3f" % (n, v) for n, v in zip(names, stage_acc)), file=sys.stderr)
+            print("stage ms/step (last step): " + ", ".join("%s=%.3f" % (n, v) for n, v in zip(names, stage_ms)), file=sys.stderr)
+            print("encoder kernel sites (last step): " + ", ".join("%s=%.3f ms x%d (%.0f %s)" % (
+                s, k["avg_launch_ms"], k["launches"], k["achieved"], k["unit"]) for s, k in kernels.items()), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             oracle_times = []
-            out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, tok_mod, retok, audio_mod, oracle_times)
+            out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times)
             # same utterances through the GPU path at the timed configuration, checked against the oracle's word times
             out["cpu_baseline"]["parity"] = parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device)
         else:

@@ -269,10 +269,26 @@ int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_o
  * engine stream: [0] log-mel, [1] encoder, [2] cross K/V projection, [3] decoder, [4] head stats,
  * [5] top-k + aggregate, [6] DTW, [7] total. Valid after a synchronize/fetch. */
 int wca_last_stage_ms(wca_engine* e, float* ms8);
-/* Dominant kernel (encoder MLP fc1 GEMM, gemm_f16_kernel<0,true,1>): number of launches in the last
- * wca_align_batch* call, their summed HIP-event duration and the algorithmic FLOPs of one launch
- * (2 * batch*1500 * 4d * d). Needs profiling enabled. */
-int wca_last_dominant_kernel_ms(wca_engine* e, int* n_launches, float* total_ms, double* flops_per_launch);
+/* Per-kernel timing of the encoder layers in the last wca_align_batch* call (profiling enabled): HIP-event pairs around
+ * every launch of one kernel site, on the stream the kernel runs on. n_launches = encoder layers; flops / bytes = the
+ * ALGORITHMIC work of one launch at the last batch size (M = batch * 1500 rows; bytes: operands read once, outputs
+ * written once, f32 residual read + written for the two read-modify-write GEMMs). */
+enum {
+  WCA_SITE_QKV = 0,   /* encoder self-attention q/k/v projection   gemm256p<0,false,1>  N = 3d, K = d   */
+  WCA_SITE_ATTN = 1,  /* encoder self-attention (flash)            attn_kernel<false,false>             */
+  WCA_SITE_OUT = 2,   /* attention out-projection + residual       gemm256p<2,false,1>  N = d,  K = d   */
+  WCA_SITE_FC1 = 3,   /* MLP fc1 + GELU                            gemm256p<0,true,1>   N = 4d, K = d   */
+  WCA_SITE_FC2 = 4,   /* MLP fc2 + residual                        gemm256p<2,false,4>  N = d,  K = 4d  */
+  WCA_SITE_LN1 = 5,   /* attn_ln                                   layernorm_f16                        */
+  WCA_SITE_LN2 = 6,   /* mlp_ln                                    layernorm_f16                        */
+  WCA_N_SITES = 7
+};
+int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms, double* flops_per_launch,
+                       double* bytes_per_launch);
+/* on (default): phase 2 (decoder, post-processing, DTW) of a batch runs on the engine's second stream beside the next
+ * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
+ * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */
+int wca_set_overlap(wca_engine* e, int on);
 /* enable/disable per-stage event recording (default off: no extra events on the stream) */
 int wca_set_profiling(wca_engine* e, int on);
 

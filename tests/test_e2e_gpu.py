@@ -139,6 +139,42 @@ def test_too_long_is_rejected(wca, setup):
         tm.get_attentions(mel, torch.zeros(10, dtype=torch.int64).cuda(), model, tok, 1501)
 
 
+def test_token_id_outside_vocabulary_is_an_error_not_a_fault(wca, setup):
+    """A token id >= n_vocab (tokenizer / checkpoint mismatch) must surface as WCA_ERR_INVALID -- through the synchronous
+    get_attentions and through the fused path's fetch -- instead of an out-of-bounds read of the embedding table."""
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 3, 32000, 12)
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    bad = list(tokens)
+    bad[5] = dims.n_vocab + 7
+    with pytest.raises(wca._lib.WcaError, match="vocabulary"):
+        tm.get_attentions(mel, torch.tensor(bad).cuda(), model, tok, 100, medfilt_width=3)
+    opts = model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3)
+    with pytest.raises(wca._lib.WcaError, match="vocabulary"):
+        model.align_batch(torch.from_numpy(pcm[None]).cuda(), [len(pcm)], torch.tensor([bad]).cuda(), [len(bad)], [100], opts)
+    # the engine is still usable and the good tokens give the usual result
+    w, _ = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, 100, medfilt_width=3)
+    assert torch.isfinite(w).all()
+
+
+def test_get_attentions_does_not_clobber_a_queued_encode(wca, setup):
+    """wca_get_attentions takes a FREE cross-K/V slot: a batch queued by encode_batch (slot 0) and aligned afterwards
+    must give the same frames as when nothing ran in between."""
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    pa, _, tta, toksa = _utt(syn, rt, tok, 61, 48000, 20)
+    pb, _, ttb, toksb = _utt(syn, rt, tok, 62, 64000, 26)
+    opts = model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3)
+    ta = torch.tensor([toksa]).cuda()
+    want, _ = model.align_batch(torch.from_numpy(pa[None]).cuda(), [len(pa)], ta, [len(toksa)], [150], opts)
+    model.encode_batch(pcm=torch.from_numpy(pa[None]).cuda(), n_samples=[len(pa)])
+    melb = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pb)), 80, model=model)
+    tm.get_attentions(melb, torch.tensor(toksb).cuda(), model, tok, 200, medfilt_width=3)   # must not overwrite A's K/V
+    got, _ = model.align_batch(None, None, ta, [len(toksa)], [150], opts)
+    assert np.array_equal(got, want)
+
+
 def test_north_star_config_parity_medium_dims(wca):
     """The headline configuration at the bench's precision and batch size: whisper-medium dimensions, PEAKY seeded
     weights (cross_qk_std=0.08: sharp maps, so f16 operand rounding can move heads / boundaries), 10 s audio, 64-char

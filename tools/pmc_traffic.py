@@ -27,22 +27,42 @@ def per_launch(d, counter, needle):
     return sum(v) / len(v), len(v)
 
 
+SITES = {  # site -> (kernel-name substring, lambda(M, d) -> (N, K), read-modify-write f32 residual?)
+    "qkv": ("gemm256p_f16_kernel<0, false, 1, false>", lambda d: (3 * d, d), False),
+    "out_proj": ("gemm256p_f16_kernel<2, false, 1, false>", lambda d: (d, d), True),
+    "fc1": ("gemm256p_f16_kernel<0, true, 1, false>", lambda d: (4 * d, d), False),
+    "fc2": ("gemm256p_f16_kernel<2, false, 4, false>", lambda d: (d, 4 * d), True),
+    "attention": ("attn_kernel<false, false, false>", None, False),
+}
+
+
 def main():
-    fetch_dir, write_dir, out = sys.argv[1:4]
-    needle = sys.argv[4] if len(sys.argv) > 4 else "gemm256p_f16_kernel<0, true, 1, false>"
+    """usage: pmc_traffic.py <FETCH_SIZE pass dir> <WRITE_SIZE pass dir> <out.json> <site> [batch] [model] [d]"""
+    fetch_dir, write_dir, out, site = sys.argv[1:5]
+    batch = int(sys.argv[5]) if len(sys.argv) > 5 else 64
+    model = sys.argv[6] if len(sys.argv) > 6 else "medium"
+    d = int(sys.argv[7]) if len(sys.argv) > 7 else 1024
+    needle, nk, rmw = SITES[site]
     fetch_kb, n = per_launch(fetch_dir, "FETCH_SIZE", needle)
     write_kb, _ = per_launch(write_dir, "WRITE_SIZE", needle)
-    # rocprofv3 reports both derived counters in KiB-like units of 1024 bytes? No: in KB = 1000? They are "KBytes" = value * 1024 / 1024:
-    # FETCH_SIZE = TCC_EA0_RDREQ_32B*32 + (RDREQ - RDREQ_32B)*64 bytes / 1024 -> kilobytes of 1024 bytes.
+    # rocprofv3's derived FETCH_SIZE / WRITE_SIZE are in units of 1024 bytes
     fetch_b, write_b = fetch_kb * 1024.0, write_kb * 1024.0
-    M, N, K = 96000, 4096, 1024
+    M = batch * 1500
+    if nk is not None:
+        N, K = nk(d)
+        algo = (M * K + N * K) * 2 + N * 4 + (M * N * 8 if rmw else M * N * 2)
+    else:
+        N = K = None
+        algo = (M * 3 * d + M * d) * 2
+    import subprocess
+    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     res = {
-        "kernel": needle, "M": M, "N": N, "K": K, "launches_averaged": n,
+        "site": site, "kernel": needle, "batch": batch, "model": model, "M": M, "N": N, "K": K, "launches_averaged": n, "commit": head,
         "FETCH_SIZE_raw_bytes": fetch_b, "FETCH_SIZE_corrected_x2_bytes": 2.0 * fetch_b, "WRITE_SIZE_bytes": write_b,
         "traffic_bytes_per_launch": 2.0 * fetch_b + write_b,
-        "algorithmic_bytes_per_launch": (M * K + N * K + M * N) * 2 + N * 4,
-        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 1 "
-                "--no-cpu-baseline` (batch 64); FETCH_SIZE doubled per the gfx950 correction (128-B requests tallied as 64 B). "
+        "algorithmic_bytes_per_launch": algo,
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `python3 bench.py --steps 2 --warmup 1 "
+                "--no-cpu-baseline`; FETCH_SIZE doubled per the gfx950 correction (128-B requests tallied as 64 B). "
                 "FETCH counts L2 misses including Infinity-Cache hits, i.e. it is L2<->fabric traffic, an upper bound of HBM bytes.",
     }
     json.dump(res, open(out, "w"), indent=1)

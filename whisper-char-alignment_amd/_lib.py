@@ -38,6 +38,7 @@ class DecodeOpts(C.Structure):
 
 
 AGGR_MEAN, AGGR_TOPK = 0, 1
+SITES = {"qkv": 0, "attention": 1, "out_proj": 2, "fc1": 3, "fc2": 4, "ln1": 5, "ln2": 6}  # WCA_SITE_* of include/wca.h
 DTYPE_F32, DTYPE_F16 = 0, 1
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -80,7 +81,8 @@ SIGNATURES = {
     "wca_test_encoder": (_i, [_vp, _vp, _i, _vp]),
     "wca_last_stage_ms": (_i, [_vp, _pf]),
     "wca_set_profiling": (_i, [_vp, _i]),
-    "wca_last_dominant_kernel_ms": (_i, [_vp, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double)]),
+    "wca_last_kernel_ms": (_i, [_vp, _i, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "wca_set_overlap": (_i, [_vp, _i]),
 }
 
 _lib = None

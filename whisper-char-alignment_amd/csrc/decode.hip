@@ -15,9 +15,10 @@ namespace wca {
 namespace {
 
 __global__ __launch_bounds__(256) void embed_step_kernel(const int* __restrict__ tokens, int T_max, int t, const half_t* __restrict__ tok_emb,
-                                                         const float* __restrict__ pos_emb, float* __restrict__ x, int d) {
+                                                         const float* __restrict__ pos_emb, float* __restrict__ x, int d, int n_vocab) {
   const int b = blockIdx.x;
-  const long tok = tokens[(long)b * T_max + t];
+  long tok = tokens[(long)b * T_max + t];
+  tok = (tok < 0 || tok >= n_vocab) ? 0 : tok;  // ids come from decode_select / the validated prompt; never read out of bounds
   const half_t* e = tok_emb + tok * d;
   const float* p = pos_emb + (long)t * d;
   float* o = x + (long)b * d;
@@ -206,8 +207,8 @@ hipError_t launch_token_prob(const float* logits, int ld, int n_vocab, int token
 }
 
 hipError_t launch_embed_step(const int* tokens, int T_max, int t, const half_t* tok_emb, const float* pos_emb, float* x, int B, int d,
-                             hipStream_t s) {
-  hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, tokens, T_max, t, tok_emb, pos_emb, x, d);
+                             int n_vocab, hipStream_t s) {
+  hipLaunchKernelGGL(embed_step_kernel, dim3(B), dim3(256), 0, s, tokens, T_max, t, tok_emb, pos_emb, x, d, n_vocab);
   return hipGetLastError();
 }
 

@@ -87,12 +87,18 @@ __global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __re
   }
 }
 
+// A token id outside [0, n_vocab) (tokenizer / checkpoint mismatch) must not become an out-of-bounds read of the
+// embedding table: the row is embedded as token 0 and *err is raised; the host reports WCA_ERR_INVALID at its next sync.
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const half_t* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, float* __restrict__ x, int B, int n,
-                                                    int d) {
+                                                    int d, int n_vocab, int* __restrict__ err) {
   const int row = blockIdx.x;  // b*n + i
   const int i = row % n;
-  const long tok = tokens[row];
+  long tok = tokens[row];
+  if (tok < 0 || tok >= n_vocab) {
+    if (threadIdx.x == 0 && err) atomicOr(err, 1);
+    tok = 0;
+  }
   const half_t* e = tok_emb + tok * d;
   const float* p = pos_emb + (long)i * d;
   float* o = x + (long)row * d;
@@ -132,9 +138,9 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
 }
 
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x, int B, int n,
-                        int d, hipStream_t s) {
+                        int d, int n_vocab, int* err, hipStream_t s) {
   if (B * n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embed_kernel, dim3(B * n), dim3(256), 0, s, tokens, tok_emb, pos_emb, x, B, n, d);
+  hipLaunchKernelGGL(embed_kernel, dim3(B * n), dim3(256), 0, s, tokens, tok_emb, pos_emb, x, B, n, d, n_vocab, err);
   return hipGetLastError();
 }
 

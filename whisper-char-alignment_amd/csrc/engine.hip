@@ -148,6 +148,8 @@ struct wca_engine {
   int* meta_dev = nullptr;   // META_SLOTS x 4 x max_batch ints: n_samples, n_tok, n_frames, dtwN
   int* meta_host = nullptr;  // pinned mirror
   int meta_slot = 0;
+  int* err_dev = nullptr;    // device flag raised by kernels on invalid input (token id outside the vocabulary)
+  int* err_host = nullptr;   // pinned: read back by the synchronous entry points
 
   // ---- run-time sized buffers
   GrowBuf cap, wws, colnorm, scores, sel, selsc, matrix, trace, path, pathlen, jump, tmp0, tmp1;
@@ -170,7 +172,9 @@ struct wca_engine {
   int last_batch = 0;
 
   hipEvent_t ev[9] = {};
-  hipEvent_t kev[64] = {};   // start/stop pairs around the encoder MLP fc1 GEMM of each layer (dominant kernel)
+  // start/stop pairs around each kernel of every encoder layer (profiling only): site = WCA_SITE_* of include/wca.h
+  hipEvent_t kev[WCA_N_SITES][32][2] = {};
+  bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   bool ev_valid = false;
   float stage_ms[8] = {};
 };
@@ -275,6 +279,7 @@ size_t layout_arena(wca_engine* e, char* base) {
   e->q_d = carve<half_t>(cur, B * MAX_TOK * dt);
   e->hid_d = carve<half_t>(cur, B * MAX_TOK * 4 * dt);
   e->meta_dev = carve<int>(cur, (size_t)META_SLOTS * 4 * B);
+  e->err_dev = carve<int>(cur, 64);
   return (size_t)(cur - base) + 4096;
 }
 
@@ -436,10 +441,17 @@ int run_encoder(wca_engine* e, int B) {
   }
   const int M = B * N_CTX;
   const float scale = 1.0f / std::sqrt((float)(d / H));
+  auto mark = [&](int site, int li, int which) {
+    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[site][li][which], s);
+  };
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
+    mark(WCA_SITE_LN1, li, 0);
     HIPCHK(launch_layernorm_f16(e->x, l.ln1_g, l.ln1_b, e->xn, M, d, 1e-5f, s));
+    mark(WCA_SITE_LN1, li, 1);
+    mark(WCA_SITE_QKV, li, 0);
     HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0, 1));
+    mark(WCA_SITE_QKV, li, 1);
     AttnArgs a{};
     a.Q = e->qkv;
     a.K = e->qkv + d;
@@ -455,13 +467,21 @@ int run_encoder(wca_engine* e, int B) {
     a.B = B;
     a.scale = scale;
     a.causal = 0;
+    mark(WCA_SITE_ATTN, li, 0);
     HIPCHK(launch_attention(a, s));
+    mark(WCA_SITE_ATTN, li, 1);
+    mark(WCA_SITE_OUT, li, 0);
     HIPCHK(gemm(s, e->att, d, l.out_w, d, l.out_b, e->x, d, M, d, d, 0, 2, 1));
+    mark(WCA_SITE_OUT, li, 1);
+    mark(WCA_SITE_LN2, li, 0);
     HIPCHK(launch_layernorm_f16(e->x, l.ln2_g, l.ln2_b, e->xn, M, d, 1e-5f, s));
-    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[2 * li], s);
+    mark(WCA_SITE_LN2, li, 1);
+    mark(WCA_SITE_FC1, li, 0);
     HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0, 1));
-    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[2 * li + 1], s);
-    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2, 1));
+    mark(WCA_SITE_FC1, li, 1);
+    mark(WCA_SITE_FC2, li, 0);
+    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2, 4));
+    mark(WCA_SITE_FC2, li, 1);
   }
   HIPCHK(launch_layernorm_f16(e->x, e->lnpost_g, e->lnpost_b, e->xn, M, d, 1e-5f, s));
   return WCA_OK;
@@ -488,7 +508,7 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   if (!kvbuf) kvbuf = e->kv;
   const int M = B * n;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
-  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, s));
+  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->dec[li];
     HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, M, dt, 1e-5f, s));
@@ -562,7 +582,7 @@ int run_decode_step(wca_engine* e, hipStream_t s, const half_t* kvbuf, const int
   const float scale = 1.0f / std::sqrt((float)(dt / H));
   half_t* cache = (half_t*)e->dec_cache.p;
   const size_t plane = (size_t)B * T_max * dt;  // one layer's K (or V) cache
-  HIPCHK(launch_embed_step(tokens, T_max, t, e->tok_emb, e->dec_pos, e->xd, B, dt, s));
+  HIPCHK(launch_embed_step(tokens, T_max, t, e->tok_emb, e->dec_pos, e->xd, B, dt, D.n_vocab, s));
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->dec[li];
     half_t* kc = cache + (size_t)(2 * li) * plane;
@@ -875,8 +895,12 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   HIPCHK(hipMemset(e->aslab, 0, abytes));  // zero pad rows of mel_tm / h1pad and all slack
   layout_arena(e, e->aslab);
   HIPCHK(hipHostMalloc((void**)&e->meta_host, sizeof(int) * META_SLOTS * 4 * max_batch, hipHostMallocDefault));
+  HIPCHK(hipHostMalloc((void**)&e->err_host, sizeof(int) * 4, hipHostMallocDefault));
+  e->err_host[0] = 0;
   for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
-  for (auto& ev : e->kev) HIPCHK(hipEventCreate(&ev));
+  for (auto& site : e->kev)
+    for (auto& layer : site)
+      for (auto& ev : layer) HIPCHK(hipEventCreate(&ev));
   for (auto& ev : e->res_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   e->ev_valid = true;
   // constant tables of the STFT
@@ -905,6 +929,7 @@ void wca_engine_destroy(wca_engine* e) {
   if (e->wslab) (void)hipFree(e->wslab);
   if (e->aslab) (void)hipFree(e->aslab);
   if (e->meta_host) (void)hipHostFree(e->meta_host);
+  if (e->err_host) (void)hipHostFree(e->err_host);
   if (e->dec_done_host) (void)hipHostFree(e->dec_done_host);
   e->dec_cache.release();
   e->dec_tokens.release();
@@ -918,7 +943,9 @@ void wca_engine_destroy(wca_engine* e) {
   if (e->ev_valid)
   {
     for (auto& ev : e->ev) (void)hipEventDestroy(ev);
-    for (auto& ev : e->kev) (void)hipEventDestroy(ev);
+    for (auto& site : e->kev)
+      for (auto& layer : site)
+        for (auto& ev : layer) (void)hipEventDestroy(ev);
   }
   for (auto& ev : e->ev_kv)
     if (ev) (void)hipEventDestroy(ev);
@@ -956,21 +983,41 @@ int wca_last_stage_ms(wca_engine* e, float* ms8) {
   return WCA_OK;
 }
 
-int wca_last_dominant_kernel_ms(wca_engine* e, int* n_launches, float* total_ms, double* flops_per_launch) {
-  if (!e || !n_launches || !total_ms || !flops_per_launch) return fail(WCA_ERR_INVALID, "null argument");
+int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms, double* flops_per_launch, double* bytes_per_launch) {
+  if (!e || !n_launches || !total_ms || !flops_per_launch || !bytes_per_launch) return fail(WCA_ERR_INVALID, "null argument");
+  if (site < 0 || site >= WCA_N_SITES) return fail(WCA_ERR_INVALID, "site %d outside [0,%d)", site, WCA_N_SITES);
   if (!e->profiling) return fail(WCA_ERR_STATE, "profiling disabled");
   HIPCHK(hipEventSynchronize(e->ev[8]));
   const int nl = e->dims.n_audio_layer < 32 ? e->dims.n_audio_layer : 32;
   float tot = 0.f;
   for (int i = 0; i < nl; ++i) {
     float ms = 0.f;
-    HIPCHK(hipEventElapsedTime(&ms, e->kev[2 * i], e->kev[2 * i + 1]));
+    HIPCHK(hipEventElapsedTime(&ms, e->kev[site][i][0], e->kev[site][i][1]));
     tot += ms;
   }
   *n_launches = nl;
   *total_ms = tot;
-  const double d = e->dims.n_audio_state;
-  *flops_per_launch = 2.0 * ((double)e->last_batch * N_CTX) * (4.0 * d) * d;
+  // algorithmic work of ONE launch at the last batch size (M = batch * 1500 rows, d = n_audio_state)
+  const double d = e->dims.n_audio_state, M = (double)e->last_batch * N_CTX, H = e->dims.n_audio_head;
+  double fl = 0, by = 0;
+  switch (site) {
+    case WCA_SITE_QKV: fl = 2 * M * 3 * d * d; by = 2 * (M * d + 3 * d * d + M * 3 * d); break;
+    case WCA_SITE_ATTN: fl = 4.0 * e->last_batch * H * (double)N_CTX * N_CTX * 64; by = 2 * (M * 3 * d + M * d); break;
+    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d; break;          // f32 residual read + write
+    case WCA_SITE_FC1: fl = 2 * M * 4 * d * d; by = 2 * (M * d + 4 * d * d + M * 4 * d); break;
+    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d; break;
+    case WCA_SITE_LN1:
+    case WCA_SITE_LN2: fl = 8 * M * d; by = 6 * M * d; break;                                    // read f32, write f16
+  }
+  *flops_per_launch = fl;
+  *bytes_per_launch = by;
+  return WCA_OK;
+}
+
+int wca_set_overlap(wca_engine* e, int on) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the batches in flight before changing the stream layout");
+  e->overlap = on != 0;
   return WCA_OK;
 }
 
@@ -1117,13 +1164,19 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
   dim3 grid((unsigned)((nel + 255) / 256), batch);
   hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
   HIPCHK(hipGetLastError());
+  // cross-K/V go into a slot no queued batch (wca_encode_batch / wca_greedy_decode / an un-fetched alignment) still needs
+  const int slot = take_kv_slot(e);
+  if (slot < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
+  half_t* kvbuf = slot ? e->kv_alt : e->kv;
+  HIPCHK(hipMemsetAsync(e->err_dev, 0, sizeof(int), e->stream));
   rc = run_encoder(e, batch);
   if (rc) return rc;
-  rc = run_cross_kv(e, batch);
+  rc = run_cross_kv(e, batch, kvbuf);
   if (rc) return rc;
   HIPCHK(e->cap.ensure(sizeof(float) * (size_t)batch * LH * n_tok * Fpad));
-  rc = run_decoder(e, tokens_dev, batch, n_tok, (float*)e->cap.p, Fpad, Fmax, logits_out_dev);
+  rc = run_decoder(e, tokens_dev, batch, n_tok, (float*)e->cap.p, Fpad, Fmax, logits_out_dev, nullptr, kvbuf);
   if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(e->err_host, e->err_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e->colnorm.ensure(sizeof(float) * (size_t)batch * LH * Fmax));
   HIPCHK(e->scores.ensure(sizeof(float) * (size_t)batch * LH));
   HeadStatsArgs h{};
@@ -1147,6 +1200,10 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
   h.w_row = 1.f;
   h.w_cov = 0.f;
   HIPCHK(launch_head_stats(h, e->stream));
+  // this entry point is the reference's synchronous per-utterance call: the host learns here whether a token id was
+  // outside the vocabulary (the row was embedded as token 0, never read out of bounds)
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->err_host[0]) return fail(WCA_ERR_INVALID, "a token id is outside the model's vocabulary [0, %d) (tokenizer / checkpoint mismatch?)", D.n_vocab);
   return WCA_OK;
 }
 
@@ -1518,10 +1575,11 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     }
   }
   half_t* kvbuf = bs ? e->kv_alt : e->kv;
-  hipStream_t s2 = e->stream2;
+  hipStream_t s2 = e->overlap ? e->stream2 : e->stream;
   // ---- phase 2 on `stream2`: decoder with capture, head statistics, top-k, aggregation, DTW, D2H. These are
   // latency-bound kernels with few workgroups; on their own stream they overlap the NEXT batch's phase 1.
   HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
+  HIPCHK(hipMemsetAsync(e->err_dev, 0, sizeof(int), s2));
   HIPCHK(e->cap.ensure(sizeof(float) * (size_t)batch * LH * n_tok_max * Fpad));
   rc = run_decoder(e, tokens_dev, batch, n_tok_max, (float*)e->cap.p, Fpad, Fmax, nullptr, s2, kvbuf);
   if (rc) return rc;
@@ -1565,8 +1623,11 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   // results -> pinned staging (ring of 2 so the host can post-process batch i while batch i+1 runs)
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
   const int rs = (int)(e->enq_count & 1);
-  rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1));
+  rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1) + 1);
   if (rc) return rc;
+  // the invalid-token flag of this batch travels with its results (last int of the staging slot)
+  HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1), e->err_dev, sizeof(int),
+                        hipMemcpyDeviceToHost, s2));
   if (n_tok_max - o->sot_len - 1 >= 1)
     HIPCHK(hipMemcpyAsync(e->res_host[rs], e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, s2));
   if (k > 0)
@@ -1747,6 +1808,9 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
   if (e->res_kvslot[rs] >= 0) e->slot_busy[e->res_kvslot[rs]] = false;
   e->res_kvslot[rs] = -1;
   e->fetch_count++;
+  const int kk = e->res_topk[rs];
+  if (e->res_host[rs][(size_t)batch * n_tok_max + (size_t)batch * (kk > 0 ? kk : 1)])
+    return fail(WCA_ERR_INVALID, "a token id is outside the model's vocabulary [0, %d) (tokenizer / checkpoint mismatch?)", e->dims.n_vocab);
   return WCA_OK;
 }
 

@@ -802,6 +802,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       case 1: WCA_LAUNCH_S(OM, G, 1); break;  \
       case 2: WCA_LAUNCH_S(OM, G, 2); break;  \
       case 3: WCA_LAUNCH_S(OM, G, 3); break;  \
+      case 4: WCA_LAUNCH_S(OM, G, 4); break;  \
       default: WCA_LAUNCH_S(OM, G, 0); break; \
     }                                         \
   } while (0)

@@ -31,9 +31,9 @@ struct GemmArgs {
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
-  int site;
-  int supertile;  // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)                // 0 generic, 1 encoder block, 2 decoder, 3 conv stem / cross-KV / logits: selects a distinct
-                           // kernel symbol per call site so rocprofv3 --stats separates the shapes
+  int site;                // 0 generic, 1 encoder block (QKV / out-projection / fc1), 2 decoder, 3 conv stem / cross-KV / logits,
+                           // 4 encoder fc2: selects a distinct kernel symbol per call site so rocprofv3 --stats separates them
+  int supertile;           // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -59,14 +59,15 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out,
                                 int rows, int d, float eps, hipStream_t s);
 // x[b*n + i][:] = tok_emb[tokens[b*n+i]][:] + pos_emb[i][:]
+// ids outside [0, n_vocab) are embedded as token 0 and raise *err (device int, nullable)
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x,
-                        int B, int n, int d, hipStream_t s);
+                        int B, int n, int d, int n_vocab, int* err, hipStream_t s);
 hipError_t launch_fill_f16(half_t* p, size_t n, float v, hipStream_t s);
 
 // ---------------------------------------------------------------- greedy ASR decode steps (decode.hip)
 // x[b][:] = tok_emb[tokens[b*T_max + t]][:] + pos_emb[t][:]
 hipError_t launch_embed_step(const int* tokens, int T_max, int t, const half_t* tok_emb, const float* pos_emb, float* x, int B, int d,
-                             hipStream_t s);
+                             int n_vocab, hipStream_t s);
 // k / v columns of qkv [B][3d] -> kc / vc [B][T_max][d] at position t
 hipError_t launch_kv_append(const half_t* qkv, half_t* kc, half_t* vc, int B, int T_max, int t, int d, hipStream_t s);
 // logit filters + greedy update of one decoding step (upstream decoding.py: SuppressBlank, SuppressTokens,

@@ -366,13 +366,19 @@ class WhisperAMD:
     def set_profiling(self, on):
         _lib.check(self._lib.wca_set_profiling(self._h, 1 if on else 0))
 
-    def dominant_kernel_ms(self):
-        """(launches, summed ms, flops per launch) of the encoder fc1 GEMM in the last align_batch call."""
+    def kernel_ms(self, site):
+        """(launches, summed ms, algorithmic flops per launch, algorithmic bytes per launch) of one encoder kernel site
+        ('qkv' | 'attention' | 'out_proj' | 'fc1' | 'fc2' | 'ln1' | 'ln2') in the last align_batch call (profiling on)."""
         n = C.c_int(0)
         ms = C.c_float(0)
         fl = C.c_double(0)
-        _lib.check(self._lib.wca_last_dominant_kernel_ms(self._h, C.byref(n), C.byref(ms), C.byref(fl)))
-        return n.value, ms.value, fl.value
+        by = C.c_double(0)
+        _lib.check(self._lib.wca_last_kernel_ms(self._h, _lib.SITES[site], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
+        return n.value, ms.value, fl.value, by.value
+
+    def set_overlap(self, on):
+        """Phase 2 on its own stream (default) or everything on one stream (clean per-kernel profiles)."""
+        _lib.check(self._lib.wca_set_overlap(self._h, 1 if on else 0))
 
     def last_stage_ms(self):
         ms = (C.c_float * 8)()
