@@ -92,6 +92,21 @@ def build_inputs(syn, tok_mod, retok, args, n_batches, rank, world, device):
     return tok, batches
 
 
+def host_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a
+    share of a large host -- 16 cores per GPU on this pool, the default cap; WCA_CPU_THREADS overrides -- and over-subscribing
+    the share stalls the baseline)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("WCA_CPU_THREADS", "16"))))
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -106,7 +121,7 @@ def cpu_model():
 def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
     """Oracle (CPU restatement of the reference pipeline, kind 'port') on a bounded sample, every host core."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     tok = tokenizer_ref.CharTokenizer()
     ref = whisper_ref.WhisperRef(sd, dims)
@@ -125,10 +140,11 @@ def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
         _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", args.topk)
         dt = time.perf_counter() - t0
         oracle_times.append((10_000 + u, text, np.asarray(st), np.asarray(en)))
+        print("cpu baseline utterance %d/%d: %.2f s" % (u, args.cpu_utts, dt), file=sys.stderr, flush=True)  # progress (long, silent otherwise)
         if u > 0:
             times.append(dt)
     per = float(np.mean(times))
-    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "cpu": cpu_model(), "kind": "port",
+    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "host_cpu_count": os.cpu_count(), "cpu": cpu_model(), "kind": "port",
             "sample": "%d utterances (after 1 warm-up) of the same synthetic workload, batch 1 serial like infer_ali.py:48,57, "
                       "PyTorch-CPU fp32 forward (torch.set_num_threads(%d)) + oracle post-processing, %.2f s/utt" % (len(times), cores, per)}
 

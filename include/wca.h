@@ -250,7 +250,9 @@ int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, c
  * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
                           int out_mode, unsigned long long* dbg_dev);
-/* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL */
+/* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL.
+ * causal: bit 0 = causal mask; bits 8-9 = kernel variant (0 auto, 1 the 16x16x32-MFMA kernel, 2 the 32x32x16-MFMA
+ * kernel that serves the encoder's un-masked self-attention) */
 int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
                        float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
 /* diagnostic build with s_memtime stamps per key tile ([4 blocks][4 waves][32 tiles][8] u64); tools/attn_stamps.py */

@@ -223,3 +223,58 @@ def test_probe_oracle_cli(corpus):
     probe.infer_dataset(args)
     res = json.load(open(glob.glob(str(out / "*.json"))[0]))
     assert 0.0 <= res["hit_rate"] <= 1.0 and "f1" in res
+
+
+def test_reference_readme_snippet_runs_on_dropin_modules(tmp_path):
+    """The reference's README example (README.md:78-131), line for line except torchaudio.load, with
+    whisper-char-alignment_amd/dropin first on sys.path: `import whisper`, `from timing import get_attentions, force_align`,
+    `from retokenize import encode, remove_punctuation` resolve to this engine. A tiny random checkpoint in openai format
+    stands in for medium.pt (the known answer itself is tests/test_readme_kat_gpu.py). Runs in a subprocess."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = """
+import sys, os, dataclasses
+sys.path.insert(0, %(dropin)r)
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, importlib
+syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+eng = importlib.import_module("whisper-char-alignment_amd.engine")
+dims = eng.dims_for("tiny")
+torch.save({"dims": dataclasses.asdict(dims), "model_state_dict": syn.random_state_dict(dims, seed=1, cross_qk_std=0.1)}, %(ckpt)r)
+
+# ---- README.md:78-131 ----
+from timing import get_attentions, force_align
+from retokenize import encode, remove_punctuation
+import whisper
+from whisper.tokenizer import get_tokenizer
+
+AUDIO_SAMPLES_PER_TOKEN = whisper.audio.HOP_LENGTH * 2
+AUDIO_TIME_PER_TOKEN = AUDIO_SAMPLES_PER_TOKEN / whisper.audio.SAMPLE_RATE
+DEVICE = 'cuda:0'
+model = whisper.load_model("tiny", download_root=%(wdir)r)
+model.to(DEVICE)
+options = whisper.DecodingOptions(language="en")
+tokenizer = get_tokenizer(model.is_multilingual, language='English')
+audio = torch.from_numpy(np.load(%(pcm)r).astype(np.float32) / 32768.0)   # torchaudio.load(sample_audio) stand-in
+audio = audio.squeeze()
+duration = len(audio.flatten())
+audio = whisper.pad_or_trim(audio.flatten())
+mel = whisper.log_mel_spectrogram(audio, 80)
+mel = mel.to(DEVICE)
+transcription = remove_punctuation("Artificial intelligence is for real.")    # (whisper.decode needs a vocabulary file)
+text_tokens = encode(transcription, tokenizer, aligned_unit_type='char')
+tokens = torch.tensor([*tokenizer.sot_sequence, tokenizer.no_timestamps, *text_tokens, tokenizer.eot]).to(DEVICE)
+max_frames = duration // AUDIO_SAMPLES_PER_TOKEN
+attn_w, logits = get_attentions(mel, tokens, model, tokenizer, max_frames, medfilt_width=3, qk_scale=1.0)
+words, start_times, end_times, ws, scores = force_align(attn_w, text_tokens, tokenizer, aligned_unit_type='char', aggregation='topk', topk=10)
+for i, word in enumerate(words[:-1]):
+    print(f"{start_times[i]:.2f} {end_times[i]:.2f} {word.strip()}")
+assert [w.strip() for w in words[:-1]] == ["Artificial", "intelligence", "is", "for", "real"]
+assert tuple(attn_w.shape) == (4, 6, len(tokens), 145) and tuple(ws.shape) == (len(text_tokens) + 1, 145) and len(scores) == 10
+assert start_times[0] == 0.0 and all(e >= s for s, e in zip(start_times, end_times)) and end_times[-1] <= 2.9
+print("snippet ok")
+""" % dict(dropin=os.path.join(root, "whisper-char-alignment_amd", "dropin"), root=root, ckpt=str(tmp_path / "tiny.pt"), wdir=str(tmp_path),
+           pcm=os.path.join(GOLD, "sample_pcm_int16.npy"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "snippet ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -337,3 +337,35 @@ def test_librispeech_dataset_flac_tree(tmp_path):
     assert data.duration_hint(2) > data.duration_hint(1)
     audio, mel, duration, text, starts, ends, fid = ds.Collate()([data[0]])
     assert fid == "1089-134686-0000" and duration == 52000
+
+
+def test_dropin_module_names_resolve():
+    """whisper-char-alignment_amd/dropin on sys.path gives the reference's own import lines (timing.py:1-10,
+    infer_ali.py:11-20, README.md:78-83) -- checked in a subprocess so that the stand-in `whisper` module does not leak
+    into this test process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from timing import get_attentions, force_align, filter_attention, default_find_alignment\n"
+        "from retokenize import encode, remove_punctuation, split_tokens_on_spaces\n"
+        "from metrics import eval_n1, eval_n1_strict, get_seg_metrics, coverage_penalty\n"
+        "from dataset import TIMIT, LibriSpeech, Collate\n"
+        "import whisper\n"
+        "from whisper.model import disable_sdpa\n"
+        "from whisper.timing import median_filter, dtw\n"
+        "from whisper.audio import HOP_LENGTH, SAMPLE_RATE, TOKENS_PER_SECOND\n"
+        "from whisper.tokenizer import get_tokenizer\n"
+        "assert (HOP_LENGTH, SAMPLE_RATE, TOKENS_PER_SECOND) == (160, 16000, 50)\n"
+        "assert whisper.audio.HOP_LENGTH * 2 == 320\n"
+        "tok = get_tokenizer(True, language='English'); assert len(tok.sot_sequence) == 3\n"
+        "opt = whisper.DecodingOptions(language='en'); assert opt.language == 'en'\n"
+        "try:\n"
+        "    whisper.load_model('medium', download_root='/nonexistent')\n"
+        "    raise SystemExit('load_model must not succeed without a local checkpoint')\n"
+        "except RuntimeError as e:\n"
+        "    assert 'never downloads' in str(e)\n"
+        "print('ok')\n" % os.path.join(root, "whisper-char-alignment_amd", "dropin"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

@@ -200,7 +200,12 @@ def _attn_ref(q, k, v, H, causal):
     (2, 3, 150, 200, 0, 0), (1, 2, 70, 70, 1, 0), (2, 6, 69, 1500, 0, 500), (1, 4, 448, 1500, 0, 1500),
     (1, 2, 300, 300, 1, 0), (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0),
     # one query row per (utterance, head): the greedy-decode kernel (cross-attention length, short / ragged caches, one key)
-    (3, 4, 1, 1500, 0, 0), (2, 6, 1, 37, 0, 0), (2, 2, 1, 1, 0, 0), (1, 3, 1, 227, 0, 0), (2, 2, 1, 1, 1, 0)])
+    (3, 4, 1, 1500, 0, 0), (2, 6, 1, 37, 0, 0), (2, 2, 1, 1, 0, 0), (1, 3, 1, 227, 0, 0), (2, 2, 1, 1, 1, 0),
+    # kernel variants forced (bits 8-9 of `causal`): 1 << 8 = the 16x16x32 kernel, 2 << 8 = the 32x32x16 encoder kernel, on
+    # ragged shapes (query / key counts not multiples of the 128-row block / 64-key tile, a single key tile, one query row)
+    (2, 3, 150, 200, 1 << 8, 0), (2, 3, 150, 200, 2 << 8, 0), (2, 6, 1500, 1500, 1 << 8, 0), (1, 2, 97, 33, 2 << 8, 0),
+    (1, 2, 33, 1500, 2 << 8, 0), (3, 1, 129, 64, 2 << 8, 0), (1, 5, 2, 65, 2 << 8, 0), (1, 20, 1500, 1500, 2 << 8, 0),
+    (1, 2, 300, 1500, 2 << 8, 0), (1, 3, 700, 129, 2 << 8, 0), (2, 3, 257, 200, 2 << 8, 0), (1, 2, 64, 192, 2 << 8, 0)])
 def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     g = torch.Generator().manual_seed(nq * 13 + nk)
     d = H * 64
@@ -209,7 +214,7 @@ def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     v = torch.randn(B, nk, d, generator=g).half()
     # a few large logits so the online-softmax rescale path is exercised
     q[:, nq // 2, :64] *= 4.0
-    o_ref, qk_ref = _attn_ref(q, k, v, H, causal)
+    o_ref, qk_ref = _attn_ref(q, k, v, H, causal & 1)
     out = torch.full((B, nq, d), float("nan"), dtype=torch.float16, device="cuda")
     cap_ld = (cap_cols + 3) & ~3
     cap = torch.full((B, H, nq, max(cap_ld, 4)), float("nan"), device="cuda") if cap_cols else None
@@ -223,6 +228,35 @@ def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
         got = cap.cpu()[..., :cap_cols]
         # f16 operands are exact, fp32 accumulation over 64 terms
         torch.testing.assert_close(got, qk_ref[..., :cap_cols], rtol=1e-4, atol=1e-4)
+
+
+def test_attention_rescale_branch_forced(eng, lib, wca):
+    """The lazy running-max scheme of both kernels takes its rescale branch only when a row's maximum grows: force it at a
+    chosen LATE key tile (one key row spiked against one query row, far above everything before it) and compare the FULL
+    output with an fp64 reference (a passing check on bounded random data never exercises that branch)."""
+    B, H, S = 1, 2, 700
+    d = H * 64
+    g = torch.Generator().manual_seed(99)
+    q = torch.randn(B, S, d, generator=g).half()
+    k = torch.randn(B, S, d, generator=g).half()
+    v = torch.randn(B, S, d, generator=g).half()
+    for row, key in ((5, 650), (300, 333), (699, 64), (130, 699)):
+        k[0, key, :64] = (q[0, row, :64].float() * 2.0).half()   # q.k*scale ~ 2*|q|^2/8 ~ 16: a jump of the row maximum
+    # growth BELOW the deferral threshold (RESCALE_THR = 8 in log2 units) at one tile, then past it at a later one: the
+    # probabilities of the first spike stay un-rescaled (up to 2^8) until the second one raises the maximum
+    for row, key, gain in ((40, 100, 0.6), (40, 400, 0.95), (520, 70, 0.5), (520, 200, 0.7), (520, 600, 1.3)):
+        k[0, key, 64:128] = (q[0, row, 64:128].float() * gain).half()
+    qh = q.double().view(B, S, H, 64).permute(0, 2, 1, 3)
+    kh = k.double().view(B, S, H, 64).permute(0, 2, 1, 3)
+    vh = v.double().view(B, S, H, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, d)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    for variant in (1, 2):
+        out = torch.full((B, S, d), float("nan"), dtype=torch.float16, device="cuda")
+        wca._lib.check(lib.wca_test_attention(eng._h, _vp(qd), _vp(kd), _vp(vd), _vp(out), None, 0, 0, B, H, S, S, variant << 8))
+        torch.cuda.synchronize()
+        err = (out.double().cpu() - ref).abs().max().item()
+        assert err <= 4e-3, (variant, err)
 
 
 def test_attention_bench_sized_encoder(eng, lib, wca):

@@ -19,14 +19,16 @@ q = torch.randn(B, S, H * 64, device="cuda").half()
 k = torch.randn(B, S, H * 64, device="cuda").half()
 v = torch.randn(B, S, H * 64, device="cuda").half()
 o = torch.empty_like(q)
-dbg = torch.zeros(4 * 4 * 32 * 8, dtype=torch.int64, device="cuda")
-for _ in range(3):
-    wca._lib.check(eng._lib.wca_test_attention_stamped(eng._h, vp(q), vp(k), vp(v), vp(o), B, H, S, S, vp(dbg)))
-torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(4, 4, 32, 8)
-for blk in (0, 2):
-    for wave in (0, 3):
-        s = d[blk, wave, 2:22, :6].astype(np.int64)
-        seg = np.diff(s, axis=1)
-        print("blk %d wave %d: vmcnt %5.0f | barrier %5.0f | dma-issue+QK %5.0f | softmax %5.0f | PV %5.0f | tile %5.0f (36 MFMAs = 576 cyc)" %
-              (blk, wave, seg[:, 0].mean(), seg[:, 1].mean(), seg[:, 2].mean(), seg[:, 3].mean(), seg[:, 4].mean(), np.diff(s[:, 0]).mean()))
+for name, var in (("16x16x32 kernel", 1), ("32x32x16 kernel", 2)):
+    dbg = torch.zeros(4 * 4 * 32 * 8, dtype=torch.int64, device="cuda")
+    for _ in range(3):
+        wca._lib.check(eng._lib.wca_test_attention_stamped(eng._h, vp(q), vp(k), vp(v), vp(o), B, H, (S if var == 0 else -((var << 20) | S)), S, vp(dbg)))
+    torch.cuda.synchronize()
+    d = dbg.cpu().numpy().reshape(4, 4, 32, 8)
+    print(name)
+    for blk in (0, 2):
+        for wave in (0, 3):
+            s = d[blk, wave, 2:22, :6].astype(np.int64)
+            seg = np.diff(s, axis=1)
+            print("  blk %d wave %d: vmcnt %5.0f | barrier %5.0f | dma-issue+QK %5.0f | softmax %5.0f | PV %5.0f | tile %5.0f" %
+                  (blk, wave, seg[:, 0].mean(), seg[:, 1].mean(), seg[:, 2].mean(), seg[:, 3].mean(), seg[:, 4].mean(), np.diff(s[:, 0]).mean()))

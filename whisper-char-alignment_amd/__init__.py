@@ -2,8 +2,10 @@
 
 The directory name contains a hyphen, so import it with
     wca = importlib.import_module("whisper-char-alignment_amd")
-or put `whisper-char-alignment_amd/dropin` on sys.path to get the reference's module names
-(`timing`, `retokenize`, `metrics`, `dataset`) unchanged.
+or put `whisper-char-alignment_amd/dropin` on sys.path to get the reference's module names unchanged: `timing`,
+`retokenize`, `metrics`, `dataset` and a `whisper` stand-in with exactly the attributes the reference touches
+(load_model from a LOCAL checkpoint, decode, DecodingOptions, pad_or_trim, log_mel_spectrogram, whisper.audio /
+.model.disable_sdpa / .timing / .tokenizer), so the reference's README snippet and drivers run on this engine as written.
 
 Nothing here falls back to the CPU: libwca.so (hand-written HIP for gfx950) must be built.
 """

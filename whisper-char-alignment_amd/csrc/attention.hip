@@ -9,6 +9,8 @@
 // TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_f16) so a query row lives on one lane column and
 // the online-softmax statistics are lane-local (+2 cross-lane steps). P^T feeds the second MFMA
 // (O^T = V^T P^T) straight from registers; V^T fragments come from ds_read_b64_tr_b16.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -19,6 +21,12 @@ namespace {
 constexpr int KT = 64;               // keys per tile
 constexpr int TILE = 64 * 64;        // f16 elements of one K or V tile
 constexpr float LOG2E = 1.4426950408889634f;
+// Deferred running-max update of the lazy online softmax: a row's running maximum m is only raised (and O, l rescaled)
+// when a tile's scores exceed it by more than RESCALE_THR in the log2 domain; until then p = exp2(s' - m) may be as large as
+// 2^THR = 256 -- exact to f16's 11 bits like any other p (f16 keeps its relative precision up to 65504), sums are fp32.
+// Without the threshold the wave-uniform rescale branch fires on almost every tile (32 rows per wave: on random data at
+// least one row's maximum grows in 75-100 % of the tiles), ~90 extra vector instructions per wave-tile.
+constexpr float RESCALE_THR = 8.0f;
 
 // max over the lanes {l, l^16} / {l, l^32} without LDS: the swap returns {own, partner} in some order
 __device__ __forceinline__ float xor16_max(float v) {
@@ -36,6 +44,36 @@ __device__ __forceinline__ half4 tr_read4(const half_t* p) {
   s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WCA_LDS s16x4*)(p));
   return __builtin_bit_cast(half4, r);
 }
+
+// ---- LDS reads the compiler must not schedule or wait for itself. hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the
+// first ds_read_b64_tr_b16 *builtin* of the loop -- it cannot tell the transposed read from the LDS-DMA writes in flight --
+// which drains the K/V prefetch on every tile; and it issues a compiler-visible ds_read_b128 only right before its MFMA
+// (one read in flight, `lgkmcnt(0)` each). These inline-asm forms are invisible to that bookkeeping: the caller counts
+// lgkmcnt itself (LDS operations return in issue order) and names the destinations in the wait statement, so that no
+// consumer can be scheduled above the wait (cdna_hip_programming.md 5.7, form (ii)).
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(const WCA_LDS char*)p; }
+template <int OFF>
+__device__ __forceinline__ half8 lds_read_b128_asm(unsigned addr) {
+  half8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
+}
+template <int OFF>
+__device__ __forceinline__ half4 lds_read_tr_asm(unsigned addr) {
+  half4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
+}
+#define WCA_LGKM_WAIT4(N, A, B, C, D)                                                                         \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A), "+v"(B), "+v"(C), "+v"(D)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
+#define WCA_LGKM_WAIT8(N, A, B, C, D, E, F, G, H)                                                             \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
 
 template <bool CAUSAL, bool CAPTURE, bool STAMP = false>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
@@ -231,9 +269,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s) mx[s] = xor32_max(mx[s]);
     if (LAZY) {
-      // st holds s' - m_eff with m_eff = m_run (0 while m_run is still -inf). Growth <=> the tile maximum of that is > 0
-      // (or anything finite arrives while m_run is -inf).
-      if (__any((mx[0] > 0.f) || (mx[1] > 0.f) || (m_run[0] == -INFINITY && mx[0] != -INFINITY) ||
+      // st holds s' - m_eff with m_eff = m_run (0 while m_run is still -inf). The maximum is raised when the tile maximum of
+      // that exceeds RESCALE_THR (or anything finite arrives while m_run is -inf).
+      if (__any((mx[0] > RESCALE_THR) || (mx[1] > RESCALE_THR) || (m_run[0] == -INFINITY && mx[0] != -INFINITY) ||
                 (m_run[1] == -INFINITY && mx[1] != -INFINITY))) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -347,6 +385,321 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs a) {
       *reinterpret_cast<half4*>(op + dt * 16) = o;
     }
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Encoder self-attention (no mask, no capture; 589.8 GFLOP per layer at batch 64): the same flash structure on
+// v_mfma_f32_32x32x16_f16. Why a second kernel: the loop above is bound by VALU ISSUE, not by the matrix pipe
+// (per 64-key tile and wave 36 MFMAs = 576 pipe cycles, but ~150 vector instructions = ~740 issue cycles, and every
+// 16x16x32 MFMA holds the SIMD's vector issue for 8 of its 16 cycles: 3 waves per SIMD measured 3420 cycles per three
+// wave-tiles against 3 x (736 + 36 x 8) = 3072 of vector issue). A 32x32x16 MFMA does twice the work per 8 blocked issue
+// cycles, and in its accumulator layout a query row is ONE lane column with 16 keys per 32-key block in registers, so
+//   * S^T = K Q^T: 8 MFMAs per wave-tile (2 key blocks x 4 k-steps), accumulator initialised to -m_running (Q carries
+//     scale * log2 e), i.e. exp2 applies directly to the MFMA result;
+//   * row max: v_max3 over the lane's 32 values + one v_permlane32_swap (the other 32 keys of the row live in lane ^ 32);
+//   * P^T needs NO lane movement to become the B operand of O^T = V^T P^T: registers 8s .. 8s+7 of a key block are the
+//     fragment of k-step s, with the k order permuted (element j of lane half h = key 16s + 8(j>>2) + 4h + (j&3)); the
+//     V^T fragments are fetched with ds_read_b64_tr_b16 in exactly that key order;
+//   * row sums on the matrix pipe (ones x P^T), 4 MFMAs;
+// per wave-tile: 20 MFMAs (640 pipe cycles, 160 blocked issue cycles) and ~32 v_exp + ~60 other vector instructions.
+// Same staging as above: 256-thread workgroup, 32 query rows per wave, ring of three 64-key K/V tiles filled by LDS-DMA two
+// tiles ahead, counted vmcnt, one raw barrier per tile. K image: chunk ^ ((key >> 1) & 7) (conflict-free ds_read_b128 for
+// the 32-row A operand); V image: chunk ^ ((key & 2) << 1) (conflict-free transposed reads).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+
+template <bool STAMP>
+__global__ __launch_bounds__(256) void attn32_kernel(AttnArgs a) {
+  constexpr int NW = 4;  // waves per workgroup, 32 query rows each
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);  // [slot][K tile | V tile]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  constexpr int QB = NW * 32;  // query rows per workgroup
+  constexpr int SLOT_BYTES = 2 * TILE * (int)sizeof(half_t);  // 16 KiB: K tile | V tile
+  const int n_qt = (a.nq + QB - 1) / QB;
+  const int lid = xcd_remap(blockIdx.x, n_qt * a.H * a.B);
+  const int bh = lid / n_qt;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q_wave = (lid - bh * n_qt) * QB + wave * 32;
+  const int qrow = q_wave + l31;
+
+  // Q fragments (B operand of S^T): lane holds Q[q = l31][dim = 16 ks + 8 hh + j], pre-multiplied by scale * log2(e)
+  const float c_log2 = a.scale * LOG2E;
+  half8 qf[4];
+  {
+    const int qc = qrow < a.nq ? qrow : a.nq - 1;
+    const half_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + h * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 raw = *reinterpret_cast<const half8*>(qp + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (half_t)((float)raw[j] * c_log2);
+    }
+  }
+  const int nkt = (a.nk + KT - 1) / KT;
+  // K / V of this (batch, head) through buffer descriptors: rows past nk read as ZERO (range check, no clamping), the
+  // per-lane byte offset is fixed for the whole kernel and the tile advances through the SCALAR offset -- no vector
+  // instruction is spent on DMA addresses inside the loop
+  const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.K + (long)b * a.k_bs + h * 64), 0,
+                                                                      (int)(((long)(a.nk - 1) * a.k_rs + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(a.V + (long)b * a.v_bs + h * 64), 0,
+                                                                      (int)(((long)(a.nk - 1) * a.v_rs + 64) * 2), 0x00020000);
+  unsigned dk[8 / NW], dv[8 / NW];
+#pragma unroll
+  for (int i = 0; i < 8 / NW; ++i) {  // 8 pieces of 8 key rows per tile and operand, spread over the workgroup's waves
+    const int r = (wave * (8 / NW) + i) * 8 + (lane >> 3);
+    dk[i] = (unsigned)(r * a.k_rs * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    dv[i] = (unsigned)(r * a.v_rs * 2 + (((lane & 7) ^ ((r & 2) << 1)) << 4));
+  }
+  const unsigned k_tile_bytes = (unsigned)(KT * a.k_rs * 2), v_tile_bytes = (unsigned)(KT * a.v_rs * 2);
+  auto stage = [&](int buf, int kt) {
+    half_t* Kt = lds + buf * (2 * TILE);
+    half_t* Vt = Kt + TILE;
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      const int rbase = (wave * (8 / NW) + i) * 8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (WCA_LDS void*)(Kt + rbase * 64), 16, (int)dk[i], (int)(kt * k_tile_bytes), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (WCA_LDS void*)(Vt + rbase * 64), 16, (int)dv[i], (int)(kt * v_tile_bytes), 0, 0);
+    }
+  };
+
+  // per-lane LDS byte addresses (ring slot 0; the slot and the fragment index go into the instructions' immediate offsets)
+  // K fragment (kb, ks): key = 32 kb + l31, chunk (2 ks + hh) ^ ((key >> 1) & 7): bit 0 = hh ^ (kswz & 1), bits 1-2 = ks ^ (kswz >> 1)
+  const int kswz = (l31 >> 1) & 7;
+  const unsigned lds_base = lds_off(lds);
+  unsigned ka[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ka[ks] = lds_base + (unsigned)(l31 * 128 + 16 * ((hh ^ kswz) & 1) + 32 * (ks ^ (kswz >> 1)));
+  // V^T fragment (db, s): two transposed reads of 4 keys x 16 dims per 16-lane group:
+  //   group g = lane >> 4: lane half hh = g >> 1, dims 32 db + 16 (g & 1) + 4 p .. +3, key 16 s + 4 hh + q (+ 8 for the second read)
+  const int vq = (lane & 15) >> 2, vp = lane & 3, vg1 = (lane >> 4) & 1;
+  const int vkey0 = 4 * hh + vq;                       // key inside a 16-key step (first read); + 8 for the second
+  const int vdim0 = 16 * vg1 + 4 * vp;                 // dim inside a 32-dim block
+  // chunk of (db, dim) = 4 db + (vdim0 >> 3); the V swizzle flips chunk bit 2 with key bit 1 (= bit 1 of vkey0)
+  const int vsw = (vkey0 & 2) << 1;
+  unsigned va[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+    va[db] = lds_base + (unsigned)(2 * TILE + vkey0 * 128 + (((4 * db + (vdim0 >> 3)) ^ vsw) << 4) + 2 * (vdim0 & 7));  // V tile = slot + 8 KiB
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  half8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (half_t)1.0f;
+  float m_run = -INFINITY;  // running row maximum in the scaled log2 domain
+  float l_run = 0.f;
+  // C operand of the first S^T MFMA of every key block: -m_running in all 16 registers. It lives across tiles and is
+  // rewritten only when a row maximum is raised (an accumulator initialised per tile costs 32 v_mov per wave-tile)
+  f32x16 cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // becomes the MFMA's inline 0 operand
+
+  stage(0, 0);
+  if (nkt > 1) stage(1, 1);
+#define WCA_STAMP(IDX)                                                                      \
+  do {                                                                                     \
+    if (STAMP) {                                                                           \
+      unsigned long long t_;                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
+      __builtin_amdgcn_sched_barrier(0);                                                   \
+      if (lane == 0 && blockIdx.x < 4 && kt < 32 && wave < 4) a.dbg[((blockIdx.x * 4 + wave) * 32 + kt) * 8 + (IDX)] = t_; \
+    }                                                                                      \
+  } while (0)
+
+  // one 64-key tile in ring slot SLOT (compile time: the LDS offsets of all 24 fragment reads are immediates)
+  auto tile = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int SB = SLOT * SLOT_BYTES;
+    WCA_STAMP(0);
+    if (kt + 1 < nkt) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // this wave's four requests of tile kt + 1 stay in flight
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    WCA_STAMP(1);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    WCA_STAMP(2);
+    if (kt + 2 < nkt) stage((SLOT + 2) % 3, kt + 2);
+
+    // ---- S^T: st[kb][r] = s'(q = l31, key = 64 kt + 32 kb + (r&3) + 8 (r>>2) + 4 hh) - m_running
+    // all eight K fragments are requested at once; each key block's MFMAs start when its four have landed
+    f32x16 st[2];
+    {
+      half8 k0[4], k1[4];
+      k0[0] = lds_read_b128_asm<SB>(ka[0]);
+      k0[1] = lds_read_b128_asm<SB>(ka[1]);
+      k0[2] = lds_read_b128_asm<SB>(ka[2]);
+      k0[3] = lds_read_b128_asm<SB>(ka[3]);
+      k1[0] = lds_read_b128_asm<SB + 32 * 128>(ka[0]);
+      k1[1] = lds_read_b128_asm<SB + 32 * 128>(ka[1]);
+      k1[2] = lds_read_b128_asm<SB + 32 * 128>(ka[2]);
+      k1[3] = lds_read_b128_asm<SB + 32 * 128>(ka[3]);
+      WCA_LGKM_WAIT4(4, k0[0], k0[1], k0[2], k0[3]);
+      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0[0], qf[0], cinit, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0[ks], qf[ks], st[0], 0, 0, 0);
+      WCA_LGKM_WAIT4(0, k1[0], k1[1], k1[2], k1[3]);
+      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1[0], qf[0], cinit, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1[ks], qf[ks], st[1], 0, 0, 0);
+    }
+    // V^T fragments of the first 32 output dims: requested now, they land under the softmax
+    // (immediate offsets: key step s4 -> + 16 s4 keys x 128 B; the second read of a step + 8 keys x 128 B)
+    half4 v0a[4], v0b[4], v1a[4], v1b[4];
+    v0a[0] = lds_read_tr_asm<SB + 0 * 2048>(va[0]);
+    v0b[0] = lds_read_tr_asm<SB + 0 * 2048 + 1024>(va[0]);
+    v0a[1] = lds_read_tr_asm<SB + 1 * 2048>(va[0]);
+    v0b[1] = lds_read_tr_asm<SB + 1 * 2048 + 1024>(va[0]);
+    v0a[2] = lds_read_tr_asm<SB + 2 * 2048>(va[0]);
+    v0b[2] = lds_read_tr_asm<SB + 2 * 2048 + 1024>(va[0]);
+    v0a[3] = lds_read_tr_asm<SB + 3 * 2048>(va[0]);
+    v0b[3] = lds_read_tr_asm<SB + 3 * 2048 + 1024>(va[0]);
+    WCA_STAMP(3);
+    // keys past nk (last tile only): wave-uniform branch
+    if (kt * KT + KT > a.nk) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] = key >= a.nk ? -INFINITY : st[kb][r];
+        }
+    }
+    // row maximum of (s' - m_eff): 15 v_max3 + 1 v_max over the lane's 32 values, then the partner half (lane ^ 32)
+    float mx;
+    {
+      float m0 = max3f(st[0][0], st[0][1], st[0][2]), m1 = max3f(st[0][3], st[0][4], st[0][5]);
+      float m2 = max3f(st[0][6], st[0][7], st[0][8]), m3 = max3f(st[0][9], st[0][10], st[0][11]);
+      m0 = max3f(m0, st[0][12], st[0][13]);
+      m1 = max3f(m1, st[0][14], st[0][15]);
+      m2 = max3f(m2, st[1][0], st[1][1]);
+      m3 = max3f(m3, st[1][2], st[1][3]);
+      m0 = max3f(m0, st[1][4], st[1][5]);
+      m1 = max3f(m1, st[1][6], st[1][7]);
+      m2 = max3f(m2, st[1][8], st[1][9]);
+      m3 = max3f(m3, st[1][10], st[1][11]);
+      m0 = max3f(m0, st[1][12], st[1][13]);
+      m1 = max3f(m1, st[1][14], st[1][15]);
+      mx = fmaxf(max3f(m0, m1, m2), m3);
+      mx = xor32_max(mx);
+    }
+    // the maximum is raised when the tile maximum of (s' - m_eff) exceeds RESCALE_THR, or anything finite arrives while m_run is still -inf
+    if (__any((mx > RESCALE_THR) || (m_run == -INFINITY && mx != -INFINITY))) {
+      const float m_eff = (m_run == -INFINITY) ? 0.f : m_run;
+      const float m_new = fmaxf(m_run, mx + m_eff);
+      const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_eff;  // still to be subtracted from this tile's scores
+      const float alpha = (m_run == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] -= delta;
+      m_run = m_new;
+      const float c0 = (m_new != -INFINITY) ? -m_new : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = c0;
+    }
+    // p = exp2(s' - m); P^T fragment of k-step s (16 keys): registers 8 (s&1) .. +7 of key block s >> 1
+    half8 pf[4];
+    {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[s4][j] = (half_t)__builtin_amdgcn_exp2f(st[s4 >> 1][8 * (s4 & 1) + j]);
+      // row sums on the matrix pipe: D[i][q] = sum_k P^T[k][q] for every i (the f16-rounded probabilities that enter P.V)
+      {
+        f32x16 rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[0], zero16, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 1; s4 < 4; ++s4) rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[s4], rs, 0, 0, 0);
+        l_run += rs[0];
+      }
+      WCA_STAMP(4);
+      // ---- O^T += V^T P^T: A operand element j of lane half hh = V[key 16 s + 8 (j>>2) + 4 hh + (j&3)][d = 32 db + l31]
+      WCA_LGKM_WAIT8(0, v0a[0], v0b[0], v0a[1], v0b[1], v0a[2], v0b[2], v0a[3], v0b[3]);
+      v1a[0] = lds_read_tr_asm<SB + 0 * 2048>(va[1]);
+      v1b[0] = lds_read_tr_asm<SB + 0 * 2048 + 1024>(va[1]);
+      v1a[1] = lds_read_tr_asm<SB + 1 * 2048>(va[1]);
+      v1b[1] = lds_read_tr_asm<SB + 1 * 2048 + 1024>(va[1]);
+      v1a[2] = lds_read_tr_asm<SB + 2 * 2048>(va[1]);
+      v1b[2] = lds_read_tr_asm<SB + 2 * 2048 + 1024>(va[1]);
+      v1a[3] = lds_read_tr_asm<SB + 3 * 2048>(va[1]);
+      v1b[3] = lds_read_tr_asm<SB + 3 * 2048 + 1024>(va[1]);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const half8 vf = __builtin_shufflevector(v0a[s4], v0b[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+        ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s4], ot[0], 0, 0, 0);
+      }
+      WCA_LGKM_WAIT8(0, v1a[0], v1b[0], v1a[1], v1b[1], v1a[2], v1b[2], v1a[3], v1b[3]);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const half8 vf = __builtin_shufflevector(v1a[s4], v1b[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+        ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s4], ot[1], 0, 0, 0);
+      }
+    }
+    WCA_STAMP(5);
+  };
+  // the ring slot of tile kt is kt % 3: three tiles per trip, every slot a compile-time constant
+  for (int kt = 0; kt < nkt; kt += 3) {
+    tile(IntC<0>{}, kt);
+    if (kt + 1 < nkt) tile(IntC<1>{}, kt + 1);
+    if (kt + 2 < nkt) tile(IntC<2>{}, kt + 2);
+  }
+#undef WCA_STAMP
+
+  // ---- epilogue: ot[db][r] = O[q = l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]; the two halves of a row are swapped pairwise
+  // (v_permlane32_swap) so that each lane stores 16 contiguous bytes
+  const float inv = 1.0f / l_run;
+  half_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + h * 64;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      // groups g = 2 g2 and 2 g2 + 1 (4 dims each, at d = 32 db + 8 g + 4 hh): packed f16 x 4 = 2 dwords per group
+      unsigned w[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const half2_ pr = half2_{(half_t)(ot[db][4 * (2 * g2 + e) + 2 * k2] * inv), (half_t)(ot[db][4 * (2 * g2 + e) + 2 * k2 + 1] * inv)};
+          w[e][k2] = __builtin_bit_cast(unsigned, pr);
+        }
+      // lane half 0 keeps group 2 g2 (own dims 0-3) and receives the partner's dims 4-7 of the same group; half 1 ends up
+      // with group 2 g2 + 1: [partner's dims 0-3 | own dims 4-7]
+      unsigned lo0, lo1, hi0, hi1;
+      {
+        auto r0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+        lo0 = r0[0];
+        hi0 = r0[1];
+        lo1 = r1[0];
+        hi1 = r1[1];
+      }
+      if (qrow < a.nq) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(op + 32 * db + 16 * g2 + 8 * hh) = u32x4{lo0, lo1, hi0, hi1};
+      }
+    }
 }
 
 
@@ -471,6 +824,17 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   }
   dim3 grid(((a.nq + 127) / 128) * a.H * a.B), block(256);
   const size_t shmem = 3 * 2 * TILE * sizeof(half_t);  // 48 KiB
+  // encoder self-attention (no mask, no capture, long rows): the 32x32x16 kernel; a.variant 1 forces the 16x16x32 one, 2 the
+  // 32x32x16 one (tests)
+  static const int env_variant = getenv("WCA_ATTN_VARIANT") ? atoi(getenv("WCA_ATTN_VARIANT")) : 0;  // debugging aid
+  const int variant = a.variant ? a.variant : env_variant;
+  const bool use32 = !a.causal && !cap && (a.o_rs % 8) == 0 && variant != 1 && (a.nq >= 64 || variant == 2);
+  if (use32) {
+    dim3 g32(((a.nq + 127) / 128) * a.H * a.B), b32(256);
+    if (a.dbg) hipLaunchKernelGGL((attn32_kernel<true>), g32, b32, shmem, s, a);
+    else hipLaunchKernelGGL((attn32_kernel<false>), g32, b32, shmem, s, a);
+    return hipGetLastError();
+  }
   if (a.dbg) {
     hipLaunchKernelGGL((attn_kernel<false, false, true>), grid, block, shmem, s, a);
     return hipGetLastError();

@@ -1895,7 +1895,8 @@ static int test_attention_impl(wca_engine* e, const void* q, const void* k, cons
   a.H = H;
   a.B = B;
   a.scale = 0.125f;
-  a.causal = causal;
+  a.causal = causal & 1;
+  a.variant = (causal >> 8) & 3;  // 0 auto, 1 the 16x16x32 kernel, 2 the 32x32x16 kernel (attention.hip)
   a.dbg = dbg;
   HIPCHK(launch_attention(a, e->stream));
   return WCA_OK;
@@ -1909,7 +1910,7 @@ int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* 
 int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nk,
                                unsigned long long* dbg_dev) {
   if (!dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
-  return test_attention_impl(e, q, k, v, o, nullptr, 0, 0, B, H, nq, nk, 0, dbg_dev);
+  return test_attention_impl(e, q, k, v, o, nullptr, 0, 0, B, H, nq >= 0 ? nq : ((-nq) & 0xfffff), nk, nq >= 0 ? 0 : (((-nq) >> 20) << 8), dbg_dev);  // nq < 0: -(variant << 20 | nq)
 }
 
 int wca_test_decode_select(wca_engine* e, const float* logits_dev, int batch, int n_vocab, int32_t* tokens_dev, int T_max, int cur_len,

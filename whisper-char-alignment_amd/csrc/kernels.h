@@ -52,6 +52,7 @@ struct AttnArgs {
   float scale;                             // applied to q.k (head_dim^-0.5)
   int causal;
   unsigned long long* dbg;                 // diagnostic builds only (s_memtime stamps)
+  int variant;                             // 0 auto, 1 force the 16x16x32 kernel, 2 force the 32x32x16 kernel (tests)
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
