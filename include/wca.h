@@ -246,6 +246,11 @@ int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capa
  * 2 f32 accumulate; out_mode >> 8: force the tile shape (0 auto, 128, 256). */
 int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                   int N, int K, int gelu, int out_mode);
+/* x (f32 [M][N], read-modify-write) += A W^T + bias; xn (f16 [M][N]) = LayerNorm(x; gamma, beta, eps 1e-5): the residual
+ * GEMMs of an encoder block with the LayerNorm in their epilogue (gemm_epilogue.h). site 1 / 4 = the out-projection's /
+ * fc2's kernel symbol. WCA_ERR_INVALID where the fused form does not apply (N % 256, K % 128, fewer than 192 tiles). */
+int wca_test_gemm_ln(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* x_dev,
+                     const float* gamma_dev, const float* beta_dev, void* xn_f16_dev, int M, int N, int K, int site);
 /* diagnostic build of the pipelined 256x256 GEMM that records s_memtime stamps per K tile into dbg_dev
  * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
@@ -278,15 +283,21 @@ int wca_last_stage_ms(wca_engine* e, float* ms8);
 enum {
   WCA_SITE_QKV = 0,   /* encoder self-attention q/k/v projection   gemm256p<0,false,1>  N = 3d, K = d   */
   WCA_SITE_ATTN = 1,  /* encoder self-attention (flash)            attn_kernel<false,false>             */
-  WCA_SITE_OUT = 2,   /* attention out-projection + residual       gemm256p<2,false,1>  N = d,  K = d   */
+  WCA_SITE_OUT = 2,   /* attention out-projection + residual (+ mlp_ln: gemm256p<3,..> fused, else + layernorm launch)  */
   WCA_SITE_FC1 = 3,   /* MLP fc1 + GELU                            gemm256p<0,true,1>   N = 4d, K = d   */
-  WCA_SITE_FC2 = 4,   /* MLP fc2 + residual                        gemm256p<2,false,4>  N = d,  K = 4d  */
-  WCA_SITE_LN1 = 5,   /* attn_ln                                   layernorm_f16                        */
-  WCA_SITE_LN2 = 6,   /* mlp_ln                                    layernorm_f16                        */
+  WCA_SITE_FC2 = 4,   /* MLP fc2 + residual (+ the next attn_ln / ln_post, same two forms)                             */
+  WCA_SITE_LN1 = 5,   /* attn_ln of layer 0                                                                            */
+  WCA_SITE_LN2 = 6,   /* unused (the other LayerNorms are timed with the GEMM that feeds them: sites 2 and 4)          */
   WCA_N_SITES = 7
 };
 int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms, double* flops_per_launch,
                        double* bytes_per_launch);
+/* on: the encoder's LayerNorms run in the epilogue of the GEMM that produces their input (attention out-projection ->
+ * mlp_ln, fc2 -> the next layer's attn_ln / ln_post) where the shape allows it (>= 192 tiles, N % 256 == 0); off
+ * (default): separate LayerNorm launches. Results agree up to fp32 rounding of the row statistics (a last-bit difference
+ * of a few f16 outputs per thousand). Measured at the bench configuration: -0.15 ms per encoder layer at kernel level,
+ * +0.3 % end to end with the two-stream overlap, hence not the default. */
+int wca_set_fuse_ln(wca_engine* e, int on);
 /* on (default): phase 2 (decoder, post-processing, DTW) of a batch runs on the engine's second stream beside the next
  * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
  * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */

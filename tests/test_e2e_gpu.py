@@ -183,6 +183,35 @@ def test_get_attentions_does_not_clobber_a_queued_encode(wca, setup):
     assert np.array_equal(got, want)
 
 
+def test_layernorm_epilogue_fusion_equals_separate_launches(wca):
+    """The encoder with the LayerNorms inside the residual GEMMs' epilogues (wca_set_fuse_ln) against the same engine with
+    separate LayerNorm launches (the default), at a batch large enough for the fused form (medium width, 3 layers, B = 12): encoder outputs agree
+    to f16 rounding and the fused alignment path gives the same jump frames either way."""
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 1024, 16, 3, 51865, 448, 1024, 16, 3)
+    sd = syn.random_state_dict(dims, seed=4, cross_qk_std=0.08)
+    B = 12
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    tok = tk.get_tokenizer(True, language="English")
+    utts = [_utt(syn, rt, tok, 300 + u, 96000, 40) for u in range(B)]
+    pcm = torch.from_numpy(np.stack([u[0] for u in utts])).cuda()
+    mel = model.log_mel(pcm)
+    outs = {}
+    for fuse in (True, False):
+        model.set_fuse_ln(fuse)
+        enc = model.encode(mel).cpu()
+        opts = model.make_opts(aggregation="topk", topk=6, sot_len=3, medfilt_width=3)
+        tarr = torch.tensor([u[3] for u in utts], dtype=torch.int64).cuda()
+        jump, sel = model.align_batch(pcm, [96000] * B, tarr, [len(u[3]) for u in utts], [300] * B, opts)
+        outs[fuse] = (enc, jump.copy(), sel.copy())
+    model.set_fuse_ln(False)
+    assert torch.isfinite(outs[True][0]).all()
+    assert (outs[True][0] - outs[False][0]).abs().max().item() < 2e-2     # ln_post outputs, O(1), through 3 layers of f16 operands
+    agree = np.mean(outs[True][1][:, :41] == outs[False][1][:, :41])
+    assert agree > 0.95, agree   # identical up to a few near-tie frames (the f16 xn differ in the last bit here and there)
+    del model
+
+
 def test_north_star_config_parity_medium_dims(wca):
     """The headline configuration at the bench's precision and batch size: whisper-medium dimensions, PEAKY seeded
     weights (cross_qk_std=0.08: sharp maps, so f16 operand rounding can move heads / boundaries), 10 s audio, 64-char

@@ -181,6 +181,48 @@ def test_gemm_asymmetric_identity(eng, lib, wca, tile):
     assert torch.equal(out.cpu(), w.float().T.contiguous())
 
 
+@pytest.mark.parametrize("M,N,K,site", [(12288 + 100, 1024, 1024, 1), (12800, 1024, 4096, 4), (96000, 1024, 1024, 1),
+                                         (10240 - 37, 1280, 1280, 1), (24576 + 13, 512, 2048, 4)])
+def test_gemm_residual_layernorm_epilogue(eng, lib, wca, M, N, K, site):
+    """out_mode 3: x += A W^T + bias and xn = LayerNorm(x) in ONE persistent launch, the row statistics exchanged between
+    the N / 256 workgroups of a 256-row panel. Against fp32 torch on the GPU; rows with a large common offset (mean >> std)
+    check the Chan-merged variance; ragged M checks the tail tile."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    gamma = torch.rand(N, generator=g, device="cuda") + 0.5
+    beta = torch.randn(N, generator=g, device="cuda") * 0.3
+    x0 = torch.randn(M, N, generator=g, device="cuda") * 2.0
+    x0[5] += 300.0          # a row whose mean dwarfs its spread
+    x0[M - 1] -= 1000.0     # ... in the tail tile
+    x = x0.clone()
+    xn = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+    wca._lib.check(lib.wca_test_gemm_ln(eng._h, _vp(a), _vp(w), _vp(bias), _vp(x), _vp(gamma), _vp(beta), _vp(xn), M, N, K, site))
+    torch.cuda.synchronize()
+    worst_x = worst_n = 0.0
+    for r0 in range(0, M, 16384):
+        r1 = min(M, r0 + 16384)
+        ref_x = x0[r0:r1] + a[r0:r1].float() @ w.float().T + bias
+        ref_n = torch.nn.functional.layer_norm(ref_x, (N,), gamma, beta, 1e-5)
+        worst_x = max(worst_x, float(((x[r0:r1] - ref_x).abs() / (1.0 + ref_x.abs())).max()))
+        worst_n = max(worst_n, float((xn[r0:r1].float() - ref_n).abs().max()))
+    assert worst_x <= 2e-3, worst_x     # f16 operands, fp32 accumulation over K
+    assert worst_n <= 1.5e-2, worst_n   # f16 output of O(1) normalised values (gamma up to 1.5, beta 0.3)
+    # the separate LayerNorm kernel on the SAME updated x gives the same f16 values up to one rounding of the statistics
+    ln = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    wca._lib.check(lib.wca_test_layernorm(eng._h, _vp(x), _vp(gamma), _vp(beta), _vp(ln), M, N))
+    torch.cuda.synchronize()
+    assert float((ln.float() - xn.float()).abs().max()) <= 4e-3
+
+
+def test_gemm_residual_layernorm_rejects_unsupported_shapes(eng, lib, wca):
+    t = torch.zeros(16, device="cuda")
+    for M, N, K in ((4416, 1024, 1024), (96000, 1000, 1024), (96000, 1024, 1088)):   # too few tiles / ragged N / odd K-tile count
+        with pytest.raises(wca._lib.WcaError):
+            wca._lib.check(lib.wca_test_gemm_ln(eng._h, _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), M, N, K, 1))
+
+
 # ------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, H, causal):
     B, nq, d = q.shape

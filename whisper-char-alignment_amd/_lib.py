@@ -74,6 +74,7 @@ SIGNATURES = {
     "wca_greedy_decode": (_i, [_vp, _vp, _vp, _i64, _pi32, _i, _pi32, _i, _vp, _vp, C.POINTER(DecodeOpts), _pi32, _pi32, _pf, _pf]),
     "wca_test_decode_select": (_i, [_vp, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(DecodeOpts), _vp, _vp]),
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
+    "wca_test_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_stamped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -83,6 +84,7 @@ SIGNATURES = {
     "wca_set_profiling": (_i, [_vp, _i]),
     "wca_last_kernel_ms": (_i, [_vp, _i, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wca_set_overlap": (_i, [_vp, _i]),
+    "wca_set_fuse_ln": (_i, [_vp, _i]),
 }
 
 _lib = None

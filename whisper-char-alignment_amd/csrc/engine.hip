@@ -148,7 +148,10 @@ struct wca_engine {
   int* meta_dev = nullptr;   // META_SLOTS x 4 x max_batch ints: n_samples, n_tok, n_frames, dtwN
   int* meta_host = nullptr;  // pinned mirror
   int meta_slot = 0;
-  int* err_dev = nullptr;    // device flag raised by kernels on invalid input (token id outside the vocabulary)
+  unsigned long long* ln_stats = nullptr;  // out_mode 3 GEMMs: per-tile row statistics [n_state/256][B*1500 padded to 256]
+  unsigned* ln_cnt = nullptr;              // ... and per-panel arrival counters (zeroed by launch_gemm)
+  int n_cu = 0;
+  int* err_dev = nullptr;    // device flag raised by kernels: bit 0 token id outside the vocabulary, bit 1 LayerNorm hand-off timeout
   int* err_host = nullptr;   // pinned: read back by the synchronous entry points
 
   // ---- run-time sized buffers
@@ -174,6 +177,8 @@ struct wca_engine {
   hipEvent_t ev[9] = {};
   // start/stop pairs around each kernel of every encoder layer (profiling only): site = WCA_SITE_* of include/wca.h
   hipEvent_t kev[WCA_N_SITES][32][2] = {};
+  bool kev_set[WCA_N_SITES][32] = {};   // which (site, layer) pairs the last encoder run recorded
+  bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   bool ev_valid = false;
   float stage_ms[8] = {};
@@ -280,6 +285,11 @@ size_t layout_arena(wca_engine* e, char* base) {
   e->hid_d = carve<half_t>(cur, B * MAX_TOK * 4 * dt);
   e->meta_dev = carve<int>(cur, (size_t)META_SLOTS * 4 * B);
   e->err_dev = carve<int>(cur, 64);
+  {
+    const size_t mpad = align_up(B * N_CTX, 256);
+    e->ln_stats = carve<unsigned long long>(cur, (d / 256 + 1) * mpad);
+    e->ln_cnt = carve<unsigned>(cur, mpad / 256 + 16, 256);
+  }
   return (size_t)(cur - base) + 4096;
 }
 
@@ -300,6 +310,41 @@ hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ld
   g.out_mode = out_mode;
   g.site = site;
   return launch_gemm(g, s);
+}
+
+// x (f32 residual stream, [M][N]) += A W^T + bias, then xn (f16) = LayerNorm(x) with (gamma, beta): ONE kernel where the
+// persistent GEMM can exchange the row statistics between the workgroups of a 256-row panel (gemm_epilogue.h, out_mode 3);
+// otherwise (few tiles: the decoder, small batches) the read-modify-write GEMM followed by the LayerNorm kernel.
+int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, float* x, int M, int N,
+                     int K, const float* gamma, const float* beta, half_t* xn, int site, bool allow_fused = true) {
+  if (allow_fused && gemm_ln_supported(M, N, K, e->n_cu)) {
+    GemmArgs g{};
+    g.A = A;
+    g.lda = lda;
+    g.W = W;
+    g.ldw = ldw;
+    g.bias = bias;
+    g.C = x;
+    g.ldc = N;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.out_mode = 3;
+    g.site = site;
+    g.ln_gamma = gamma;
+    g.ln_beta = beta;
+    g.ln_out = xn;
+    g.ln_ld = N;
+    g.ln_eps = 1e-5f;
+    g.ln_stats = e->ln_stats;
+    g.ln_cnt = e->ln_cnt;
+    g.ln_err = e->err_dev;
+    HIPCHK(launch_gemm(g, s));
+    return WCA_OK;
+  }
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site));
+  HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s));
+  return WCA_OK;
 }
 
 // upload helpers: convert host tensor (f32 or f16) into device f16 / f32
@@ -441,14 +486,21 @@ int run_encoder(wca_engine* e, int B) {
   }
   const int M = B * N_CTX;
   const float scale = 1.0f / std::sqrt((float)(d / H));
+  memset(e->kev_set, 0, sizeof(e->kev_set));
   auto mark = [&](int site, int li, int which) {
-    if (e->profiling && li < 32) (void)hipEventRecord(e->kev[site][li][which], s);
+    if (e->profiling && li < 32) {
+      (void)hipEventRecord(e->kev[site][li][which], s);
+      e->kev_set[site][li] = true;
+    }
   };
+  // LayerNorms ride in the epilogue of the GEMM that produces their input (gemm_residual_ln): mlp_ln in the attention
+  // out-projection, the NEXT layer's attn_ln (ln_post after the last layer) in fc2; only layer 0's attn_ln is a launch
+  const bool fuse_ln = e->fuse_ln;
+  mark(WCA_SITE_LN1, 0, 0);
+  HIPCHK(launch_layernorm_f16(e->x, e->enc[0].ln1_g, e->enc[0].ln1_b, e->xn, M, d, 1e-5f, s));
+  mark(WCA_SITE_LN1, 0, 1);
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
-    mark(WCA_SITE_LN1, li, 0);
-    HIPCHK(launch_layernorm_f16(e->x, l.ln1_g, l.ln1_b, e->xn, M, d, 1e-5f, s));
-    mark(WCA_SITE_LN1, li, 1);
     mark(WCA_SITE_QKV, li, 0);
     HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0, 1));
     mark(WCA_SITE_QKV, li, 1);
@@ -471,19 +523,18 @@ int run_encoder(wca_engine* e, int B) {
     HIPCHK(launch_attention(a, s));
     mark(WCA_SITE_ATTN, li, 1);
     mark(WCA_SITE_OUT, li, 0);
-    HIPCHK(gemm(s, e->att, d, l.out_w, d, l.out_b, e->x, d, M, d, d, 0, 2, 1));
+    if (int rc = gemm_residual_ln(e, s, e->att, d, l.out_w, d, l.out_b, e->x, M, d, d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln)) return rc;
     mark(WCA_SITE_OUT, li, 1);
-    mark(WCA_SITE_LN2, li, 0);
-    HIPCHK(launch_layernorm_f16(e->x, l.ln2_g, l.ln2_b, e->xn, M, d, 1e-5f, s));
-    mark(WCA_SITE_LN2, li, 1);
     mark(WCA_SITE_FC1, li, 0);
     HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0, 1));
     mark(WCA_SITE_FC1, li, 1);
+    const bool last = li + 1 == D.n_audio_layer;
     mark(WCA_SITE_FC2, li, 0);
-    HIPCHK(gemm(s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, d, M, d, 4 * d, 0, 2, 4));
+    if (int rc = gemm_residual_ln(e, s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, M, d, 4 * d, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
+                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, 4, fuse_ln))
+      return rc;
     mark(WCA_SITE_FC2, li, 1);
   }
-  HIPCHK(launch_layernorm_f16(e->x, e->lnpost_g, e->lnpost_b, e->xn, M, d, 1e-5f, s));
   return WCA_OK;
 }
 
@@ -882,6 +933,7 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   e->dims = D;
   e->device = device_ordinal;
   e->max_batch = max_batch;
+  HIPCHK(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device_ordinal));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
   e->stream = e->own_stream;
@@ -988,12 +1040,14 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   if (site < 0 || site >= WCA_N_SITES) return fail(WCA_ERR_INVALID, "site %d outside [0,%d)", site, WCA_N_SITES);
   if (!e->profiling) return fail(WCA_ERR_STATE, "profiling disabled");
   HIPCHK(hipEventSynchronize(e->ev[8]));
-  const int nl = e->dims.n_audio_layer < 32 ? e->dims.n_audio_layer : 32;
+  int nl = 0;
   float tot = 0.f;
-  for (int i = 0; i < nl; ++i) {
+  for (int i = 0; i < 32; ++i) {
+    if (!e->kev_set[site][i]) continue;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->kev[site][i][0], e->kev[site][i][1]));
     tot += ms;
+    ++nl;
   }
   *n_launches = nl;
   *total_ms = tot;
@@ -1003,14 +1057,20 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   switch (site) {
     case WCA_SITE_QKV: fl = 2 * M * 3 * d * d; by = 2 * (M * d + 3 * d * d + M * 3 * d); break;
     case WCA_SITE_ATTN: fl = 4.0 * e->last_batch * H * (double)N_CTX * N_CTX * 64; by = 2 * (M * 3 * d + M * d); break;
-    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d; break;          // f32 residual read + write
+    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d + (e->fuse_ln ? 2 : 6) * M * d; break;  // f32 residual read + write, + the LayerNorm (fused: f16 out; launch: f32 in, f16 out)
     case WCA_SITE_FC1: fl = 2 * M * 4 * d * d; by = 2 * (M * d + 4 * d * d + M * 4 * d); break;
-    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d; break;
+    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d + (e->fuse_ln ? 2 : 6) * M * d; break;
     case WCA_SITE_LN1:
     case WCA_SITE_LN2: fl = 8 * M * d; by = 6 * M * d; break;                                    // read f32, write f16
   }
   *flops_per_launch = fl;
   *bytes_per_launch = by;
+  return WCA_OK;
+}
+
+int wca_set_fuse_ln(wca_engine* e, int on) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  e->fuse_ln = on != 0;
   return WCA_OK;
 }
 
@@ -1203,6 +1263,7 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
   // this entry point is the reference's synchronous per-utterance call: the host learns here whether a token id was
   // outside the vocabulary (the row was embedded as token 0, never read out of bounds)
   HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->err_host[0] & 2) return fail(WCA_ERR_HIP, "LayerNorm statistics hand-off timed out inside a GEMM epilogue (a workgroup of a row panel never arrived)");
   if (e->err_host[0]) return fail(WCA_ERR_INVALID, "a token id is outside the model's vocabulary [0, %d) (tokenizer / checkpoint mismatch?)", D.n_vocab);
   return WCA_OK;
 }
@@ -1809,7 +1870,9 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
   e->res_kvslot[rs] = -1;
   e->fetch_count++;
   const int kk = e->res_topk[rs];
-  if (e->res_host[rs][(size_t)batch * n_tok_max + (size_t)batch * (kk > 0 ? kk : 1)])
+  const int flag = e->res_host[rs][(size_t)batch * n_tok_max + (size_t)batch * (kk > 0 ? kk : 1)];
+  if (flag & 2) return fail(WCA_ERR_HIP, "LayerNorm statistics hand-off timed out inside a GEMM epilogue (a workgroup of a row panel never arrived)");
+  if (flag)
     return fail(WCA_ERR_INVALID, "a token id is outside the model's vocabulary [0, %d) (tokenizer / checkpoint mismatch?)", e->dims.n_vocab);
   return WCA_OK;
 }
@@ -1841,6 +1904,43 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   g.out_mode = out_mode & 0xff;
   g.force_tile = out_mode >> 8;  // 0 auto / 128 / 256
   HIPCHK(launch_gemm(g, e->stream));
+  return WCA_OK;
+}
+
+int wca_test_gemm_ln(wca_engine* e, const void* a, const void* w, const float* bias, float* x, const float* gamma, const float* beta,
+                     void* xn, int M, int N, int K, int site) {
+  if (!e || !a || !w || !x || !gamma || !beta || !xn) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (!gemm_ln_supported(M, N, K, e->n_cu)) return fail(WCA_ERR_INVALID, "residual + LayerNorm epilogue not available for M=%d N=%d K=%d", M, N, K);
+  const size_t mpad = align_up((size_t)M, 256);
+  HIPCHK(e->tmp0.ensure(sizeof(unsigned long long) * (size_t)(N / 256) * mpad));
+  HIPCHK(e->tmp1.ensure(sizeof(unsigned) * (mpad / 256 + 16)));
+  HIPCHK(hipMemsetAsync(e->err_dev, 0, sizeof(int), e->stream));
+  GemmArgs g{};
+  g.A = (const half_t*)a;
+  g.lda = K;
+  g.W = (const half_t*)w;
+  g.ldw = K;
+  g.bias = bias;
+  g.C = x;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.out_mode = 3;
+  g.site = site;
+  g.ln_gamma = gamma;
+  g.ln_beta = beta;
+  g.ln_out = (half_t*)xn;
+  g.ln_ld = N;
+  g.ln_eps = 1e-5f;
+  g.ln_stats = (unsigned long long*)e->tmp0.p;
+  g.ln_cnt = (unsigned*)e->tmp1.p;
+  g.ln_err = e->err_dev;
+  HIPCHK(launch_gemm(g, e->stream));
+  HIPCHK(hipMemcpyAsync(e->err_host, e->err_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  if (e->err_host[0] & 2) return fail(WCA_ERR_HIP, "LayerNorm statistics hand-off timed out");
   return WCA_OK;
 }
 

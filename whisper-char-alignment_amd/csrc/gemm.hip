@@ -366,6 +366,11 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   half_t* lds = reinterpret_cast<half_t*>(smem);
   constexpr int TILE256 = 256 * 64;
   float* bias_lds = reinterpret_cast<float*>(smem + 4 * TILE256 * sizeof(half_t));  // 2 x 256 floats after the ring
+  // OUT_MODE 3 (residual + LayerNorm): gamma | beta of the tile's columns (2 x 256 floats each, double buffered like the
+  // bias) and the statistics exchange area of epilogue_ln (2560 floats)
+  float* gamma_lds = bias_lds + 512;
+  float* beta_lds = gamma_lds + 512;
+  float* ln_lds = beta_lds + 512;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -381,6 +386,8 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // bias: 256 floats per tile, double buffered (tile parity), fetched by LDS-DMA with the tile's first operands.
   // A null bias gives a zero-record descriptor: every lane is out of range and the DMA writes zeros.
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, a.bias != nullptr ? a.N * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ln_gamma), 0, OUT_MODE == 3 ? a.N * 4 : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbeta = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.ln_beta), 0, OUT_MODE == 3 ? a.N * 4 : 0, 0x00020000);
   const int l8 = lane >> 3;
   const int rho = wave * 8 + l8;                       // LDS row (mod 64) this lane fills
   const int c0 = (lane & 7) ^ ((rho >> 1) & 7);        // global chunk that lands at chunk position lane & 7
@@ -389,7 +396,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   //   f16 out: lane fg owns columns fg*8 .. +7 and 32 + fg*8 .. +7   -> n = (nt>>1)*32 + (i>>2)*8 + (nt&1)*4 + (i&3)
   //   f32 out: lane fg owns columns nt*16 + fg*4 .. +3 (natural)      -> n = nt*16 + i
   const int nt_r = rho >> 4, i_r = rho & 15;
-  const int wsrc_row = (OUT_MODE == 0) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
+  const int wsrc_row = (OUT_MODE == 0 || OUT_MODE == 3) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
   // per-lane byte offsets inside a tile (tile base and K offset are wave-uniform and added per request)
   const unsigned va = (unsigned)(rho * a.lda + c0 * 8) * 2u;
   const unsigned vw = (unsigned)(wsrc_row * a.ldw + c0 * 8) * 2u;
@@ -412,8 +419,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   };
 
   auto stage_bias = [&](int par, int ncol0) {
-    if (wave < 4)
+    if (wave < 4) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (WCA_LDS void*)(bias_lds + par * 256 + wave * 64), 4, (ncol0 + wave * 64 + lane) * 4, 0, 0, 0);
+      if (OUT_MODE == 3) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (WCA_LDS void*)(gamma_lds + par * 256 + wave * 64), 4, (ncol0 + wave * 64 + lane) * 4, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbeta, (WCA_LDS void*)(beta_lds + par * 256 + wave * 64), 4, (ncol0 + wave * 64 + lane) * 4, 0, 0, 0);
+      }
+    }
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -458,8 +470,30 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     tn = r / rows;
     tm = st * SM + (r - tn * rows);
   };
+  // OUT_MODE 3 (LayerNorm in the epilogue): the N/256 workgroups that hold one 256-row panel wait for each other in the
+  // epilogue, so a panel's tiles must be worked on AT THE SAME TIME: round r of the 32 workgroups that share an XCD label
+  // (blockIdx % 8) covers PR = 32 / ntn whole panels x all ntn column tiles (the same L2 footprint as a supertile of PR), and
+  // the panels are dealt to the XCD labels in contiguous blocks. (With the id order above, panels straddle the XCDs' id
+  // ranges: a workgroup then waits for tiles that another XCD reaches a whole launch later.) Correctness does not depend on
+  // the placement -- a wait only needs same-round tiles of other workgroups, which never wait on this one's later rounds.
+  const int spx = G >> 3;                        // workgroups per XCD label (launch_gemm: G % 8 == 0, spx >= ntn)
+  const int PR = spx / ntn;                      // panels per round and label
+  const int lab = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int pq = ntm >> 3, prm = ntm & 7;
+  const int lab_panels = pq + (lab < prm ? 1 : 0), lab_base = lab * pq + (lab < prm ? lab : prm);
+  auto tile_of_round = [&](int round, int& tm, int& tn) -> bool {
+    tn = slot / PR;
+    const int pi = round * PR + (slot - tn * PR);
+    tm = lab_base + pi;
+    return tn < ntn && pi < lab_panels;
+  };
   int tm_, tn_;
-  tile_of(id, tm_, tn_);
+  int round = 0;
+  if (OUT_MODE == 3) {
+    if (!tile_of_round(0, tm_, tn_)) return;  // (wave-uniform: the whole workgroup has no tile)
+  } else {
+    tile_of(id, tm_, tn_);
+  }
   int m0 = tm_ * 256, n0 = tn_ * 256;
   unsigned ta = (unsigned)m0 * a.lda * 2u, tw = (unsigned)n0 * a.ldw * 2u;
 
@@ -497,10 +531,20 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   for (;;) {
     // the tile after this one (persistent launch only: gridDim.x < nwg needs nk even and >= 2, see launch_gemm)
     const int vn = v + G;
-    const bool has_next = vn < nwg;
-    const int idn = has_next ? xcd_remap(vn, nwg) : id;
+    bool has_next;
+    int idn = id;
     int tmn_, tnn_;
-    tile_of(idn, tmn_, tnn_);
+    if (OUT_MODE == 3) {
+      has_next = tile_of_round(round + 1, tmn_, tnn_);
+      if (!has_next) {
+        tmn_ = m0 >> 8;
+        tnn_ = n0 >> 8;
+      }
+    } else {
+      has_next = vn < nwg;
+      idn = has_next ? xcd_remap(vn, nwg) : id;
+      tile_of(idn, tmn_, tnn_);
+    }
     const int m0n = tmn_ * 256, n0n = tnn_ * 256;
     const unsigned tan = (unsigned)m0n * a.lda * 2u, twn = (unsigned)n0n * a.ldw * 2u;
     for (int kt = 0; kt < nk; ++kt) {
@@ -577,7 +621,11 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       typedef __attribute__((address_space(4))) GemmArgs KernArgs;
       const KernArgs* ap = (const KernArgs*)__builtin_amdgcn_kernarg_segment_ptr();
       asm volatile("" : "+s"(ap));
-      epilogue_wide<OUT_MODE, GELU, KernArgs>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64);
+      if constexpr (OUT_MODE == 3)
+        epilogue_ln<KernArgs>(*ap, acc, m0, m0 >> 8, n0 >> 8, ntn, wr, wc, fr_e, fg_e, bias_lds + par * 256 + wc * 64, gamma_lds + par * 256,
+                              beta_lds + par * 256, ln_lds);
+      else
+        epilogue_wide<OUT_MODE, GELU, KernArgs>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64);
     }
     if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
       a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 1] = __builtin_readcyclecounter();
@@ -588,6 +636,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     stage_bias(par, n0n);
     v = vn;
     id = idn;
+    ++round;
     m0 = m0n;
     n0 = n0n;
     ta = tan;
@@ -706,6 +755,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_f16_kernel(GemmArgs a) {
 
 }  // namespace
 
+bool gemm_ln_supported(int M, int N, int K, int n_cu) {
+  if (N % 256 != 0 || N > 2048 || K % 128 != 0 || M < 1) return false;  // whole tiles across the row; an even number of K tiles
+  const long tiles = (long)((M + 255) / 256) * (N / 256);
+  if (tiles < 192) return false;       // launch_gemm sends fewer tiles to the 128 x 128 kernel
+  return (n_cu >> 3) >= N / 256;       // grid = CUs (a multiple of 8): one workgroup per CU, all resident; a round of the n_cu / 8
+                                       // workgroups of an XCD label holds at least one whole panel (N / 256 tiles)
+}
+
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -806,7 +863,23 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       default: WCA_LAUNCH_S(OM, G, 0); break; \
     }                                         \
   } while (0)
-  if (a.out_mode == 0) {
+  if (a.out_mode == 3) {
+    // residual + LayerNorm epilogue: persistent 256 x 256 kernel only (every workgroup of a 256-row panel must be resident:
+    // one workgroup per CU, grid <= CUs), N a multiple of 256; the caller falls back to out_mode 2 + launch_layernorm_f16
+    // where gemm_ln_supported() says no
+    if (!gemm_ln_supported(a.M, a.N, a.K, n_cu) || a.gelu || !pipelined || a.force_tile == 258 || a.pos != nullptr || a.c_rows_per_batch != 0 || !a.ln_gamma ||
+        !a.ln_beta || !a.ln_out || !a.ln_stats || !a.ln_cnt || (a.ldc & 3) || (a.ln_ld & 7))
+      return hipErrorInvalidValue;
+    const size_t cnt_bytes = (((size_t)((a.M + 255) / 256) * sizeof(unsigned)) + 15) / 16 * 16;
+    hipError_t e = hipMemsetAsync(a.ln_cnt, 0, cnt_bytes, s);
+    if (e != hipSuccess) return e;
+    shmem += (2 * 512 + 2560) * sizeof(float);  // gamma | beta (double buffered) + the statistics exchange area
+    grid = dim3((unsigned)(n_cu & ~7));          // round-based panel walk: 8 XCD labels x n_cu / 8 workgroups (idle ones exit)
+    switch (a.site) {
+      case 4: WCA_LAUNCH_K(gemm256p_f16_kernel, 3, false, 4); break;
+      default: WCA_LAUNCH_K(gemm256p_f16_kernel, 3, false, 1); break;
+    }
+  } else if (a.out_mode == 0) {
     if (a.gelu) WCA_LAUNCH(0, true); else WCA_LAUNCH(0, false);
   } else if (a.out_mode == 1) {
     if (a.gelu) WCA_LAUNCH(1, true); else WCA_LAUNCH(1, false);

@@ -27,15 +27,28 @@ struct GemmArgs {
   int pos_period;
   int M, N, K;             // K % 64 == 0
   int gelu;                // apply exact (erf) GELU after bias
-  int out_mode;            // 0: store f16, 1: store f32, 2: f32 accumulate (C += result)
+  int out_mode;            // 0: store f16, 1: store f32, 2: f32 accumulate (C += result),
+                           // 3: f32 accumulate + LayerNorm of the updated row -> ln_out (f16); the row statistics are
+                           //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
+  // out_mode 3 only (the residual GEMMs of a transformer block, N = n_state <= 2048, a multiple of 256):
+  const float* ln_gamma;   // [N]
+  const float* ln_beta;    // [N]
+  half_t* ln_out;          // [M][ln_ld] f16: LayerNorm(C) with C the updated residual row
+  int ln_ld;
+  float ln_eps;
+  unsigned long long* ln_stats;  // workspace [N/256][ceil(M/256)*256] x {mean, M2} f32 pairs (written + read inside the launch)
+  unsigned* ln_cnt;        // workspace [ceil(M/256)] arrival counters, ZEROED by launch_gemm before the launch
+  int* ln_err;             // device int: bit 1 is raised if a workgroup gave up waiting for its panel's statistics
   int site;                // 0 generic, 1 encoder block (QKV / out-projection / fc1), 2 decoder, 3 conv stem / cross-KV / logits,
                            // 4 encoder fc2: selects a distinct kernel symbol per call site so rocprofv3 --stats separates them
   int supertile;           // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// out_mode 3 (residual + LayerNorm epilogue) is available for this shape on a device with n_cu compute units
+bool gemm_ln_supported(int M, int N, int K, int n_cu);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 // Flash-style multi-head attention with head_dim == 64 (every Whisper size).

@@ -376,6 +376,10 @@ class WhisperAMD:
         _lib.check(self._lib.wca_last_kernel_ms(self._h, _lib.SITES[site], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return n.value, ms.value, fl.value, by.value
 
+    def set_fuse_ln(self, on):
+        """LayerNorm in the residual GEMMs' epilogue (default) or as separate launches."""
+        _lib.check(self._lib.wca_set_fuse_ln(self._h, 1 if on else 0))
+
     def set_overlap(self, on):
         """Phase 2 on its own stream (default) or everything on one stream (clean per-kernel profiles)."""
         _lib.check(self._lib.wca_set_overlap(self._h, 1 if on else 0))
