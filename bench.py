@@ -138,9 +138,9 @@ def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
         tt = tokenizer_ref.encode_char(text, tok)
         tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
         w, _ = timing_ref.get_attentions(mel, tokens, ref, n_samples // 320, args.medfilt_width, 1.0)
-        _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", args.topk)
+        _words, st, en, matrix, _s = timing_ref.force_align(w, tt, tok, "char", "topk", args.topk)
         dt = time.perf_counter() - t0
-        oracle_times.append((10_000 + u, text, np.asarray(st), np.asarray(en)))
+        oracle_times.append((10_000 + u, text, np.asarray(st), np.asarray(en), matrix, list(tt)))
         print("cpu baseline utterance %d/%d: %.2f s" % (u, args.cpu_utts, dt), file=sys.stderr, flush=True)  # progress (long, silent otherwise)
         if u > 0:
             times.append(dt)
@@ -150,19 +150,37 @@ def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
                       "PyTorch-CPU fp32 forward (torch.set_num_threads(%d)) + oracle post-processing, %.2f s/utt" % (len(times), cores, per)}
 
 
+def oracle_is_ill_conditioned(matrix, tt, st, en, eps=1e-3, trials=8):
+    """Does the fp32 ORACLE's own alignment move by more than one frame when its aggregated matrix is perturbed by `eps`
+    relative gaussian noise (the size of f16 operand rounding)? For such an utterance "within one frame of the CPU path" is
+    decided by last-bit luck in any reduced-precision forward; the parity leg reports those utterances separately."""
+    from oracle import timing_ref, tokenizer_ref
+    tok = tokenizer_ref.CharTokenizer()
+    _w, word_tokens = tokenizer_ref.split_tokens_on_spaces(list(tt) + [tok.eot], tok, "char")
+    rng = np.random.default_rng(12345)
+    for _ in range(trials):
+        noisy = matrix * (1.0 + eps * torch.from_numpy(rng.standard_normal(tuple(matrix.shape)).astype(np.float32)))
+        ti, tj = timing_ref.dtw(-noisy)
+        s2, e2 = timing_ref.jumps_to_times(ti, tj, word_tokens)
+        if np.max(np.abs(s2 - st)) > 0.02 + 1e-9 or np.max(np.abs(e2 - en)) > 0.02 + 1e-9:
+            return True
+    return False
+
+
 def parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device):
     """The utterances the CPU baseline just aligned, through the GPU path inside FULL bench-sized micro-batches (so the
     persistent GEMMs, the batched attention grid and the batched DTW run at exactly the timed configuration); compares
     word start / end times with the oracle's. Not part of the timed region."""
     n_samples = int(args.seconds * 16000)
     total = within = identical = 0
+    utt_clean = utt_ill = utt_bad = off_well = utt_ill_all = 0
     invariant = True
     for lo in range(0, len(oracle_times), args.batch):
         chunk = oracle_times[lo:lo + args.batch]
-        ids = [u for u, _t, _s, _e in chunk]
+        ids = [c[0] for c in chunk]
         ids = (ids * ((args.batch + len(ids) - 1) // len(ids)))[:args.batch]  # fill the batch by repetition
         pcm = np.stack([syn.synth_audio(u, n_samples) for u in ids])
-        texts = {u: t for u, t, _s, _e in chunk}
+        texts = {c[0]: c[1] for c in chunk}
         rows, tts = [], []
         for u in ids:
             tt = retok.encode(texts[u], tok, "char")
@@ -176,16 +194,32 @@ def parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_tim
                                     [len(r) for r in rows], [n_samples // 320] * len(ids), opts)
         for j in range(len(chunk)):
             _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
-            _u, _t, rst, ren = chunk[j]
+            _u, _t, rst, ren, rmatrix, rtt = chunk[j]
+            off = 0
             for a, b in ((np.asarray(st), rst), (np.asarray(en), ren)):
                 if len(a) != len(b):
                     return {"utterances": len(oracle_times), "error": "word count differs"}
                 total += len(a)
                 within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
                 identical += int(np.sum(a == b))
+                off += int(np.sum(np.abs(a - b) > 0.02 + 1e-9))
+            ill = oracle_is_ill_conditioned(rmatrix, rtt, rst, ren)
+            utt_ill_all += int(ill)
+            if off == 0:
+                utt_clean += 1
+            elif ill:
+                utt_ill += 1
+            else:
+                utt_bad += 1
+                off_well += off
         # batch invariance: the repeated copies of an utterance inside the batch must give the same frames
         invariant = invariant and all(np.array_equal(jump[j][:len(rows[j])], jump[j % len(chunk)][:len(rows[j])]) for j in range(len(ids)))
     return {"utterances": len(oracle_times), "word_boundaries": total, "within_one_frame": within, "identical": identical,
+            "utterances_all_within": utt_clean, "utterances_ill_conditioned": utt_ill_all,
+            "utterances_with_offenders_ill_conditioned": utt_ill,
+            "utterances_with_offenders_well_conditioned": utt_bad, "offending_boundaries_in_well_conditioned_utterances": off_well,
+            "ill_conditioned_means": "the fp32 oracle's OWN path moves by more than one frame when its aggregated matrix is perturbed by "
+                                     "1e-3 relative noise (8 seeded trials): operand rounding decides such an utterance either way",
             "batch_invariant": bool(invariant), "weights": "peaky (cross_qk_std=0.08)", "tolerance": "one 20 ms encoder frame (north_star)"}
 
 

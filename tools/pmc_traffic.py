@@ -32,7 +32,7 @@ SITES = {  # site -> (kernel-name substring, lambda(M, d) -> (N, K), read-modify
     "out_proj": ("gemm256p_f16_kernel<2, false, 1, false>", lambda d: (d, d), True),
     "fc1": ("gemm256p_f16_kernel<0, true, 1, false>", lambda d: (4 * d, d), False),
     "fc2": ("gemm256p_f16_kernel<2, false, 4, false>", lambda d: (d, 4 * d), True),
-    "attention": ("attn_kernel<false, false, false>", None, False),
+    "attention": ("attn32_kernel<false>", None, False),
 }
 
 

@@ -1902,7 +1902,8 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   g.K = K;
   g.gelu = gelu;
   g.out_mode = out_mode & 0xff;
-  g.force_tile = out_mode >> 8;  // 0 auto / 128 / 256
+  g.force_tile = (out_mode >> 8) & 0xfff;  // 0 auto / 128 / 256 / 257 (persistent) / 258 (one tile per workgroup)
+  g.supertile = out_mode >> 20;             // 0 = launch_gemm's choice (tools: tile-order experiments)
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }
