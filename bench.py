@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--cpu-utts", type=int, default=32, help="utterances timed by the CPU baseline (after 1 warm-up)")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorms inside the residual GEMMs' epilogues instead of separate launches (A/B)")
+    ap.add_argument("--dec-unfused", action="store_true", help="decoder GEMMs on <= 256 rows as separate LayerNorm / GEMM launches (A/B of the few-row kernel; matters at small batch)")
     ap.add_argument("--no-overlap", action="store_true", help="phase 2 on the same stream as phase 1 (clean per-kernel rocprofv3 averages)")
     return ap.parse_args()
 
@@ -282,6 +283,8 @@ def main():
     if args.no_overlap:
         model.set_overlap(False)
     model.set_fuse_ln(bool(args.fuse_ln))
+    if args.dec_unfused:
+        model.set_decode_mode(False, 1)
     tok, batches = build_inputs(syn, tok_mod, retok, args, max(2, args.distinct_batches), rank, world, device)
     opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width,
                            qk_scale=1.0)

@@ -251,6 +251,13 @@ int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, c
  * fc2's kernel symbol. WCA_ERR_INVALID where the fused form does not apply (N % 256, K % 128, fewer than 192 tiles). */
 int wca_test_gemm_ln(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, float* x_dev,
                      const float* gamma_dev, const float* beta_dev, void* xn_f16_dev, int M, int N, int K, int site);
+/* The few-row GEMM of the greedy-decode steps (gemm_rows.hip): C [M][N] = epilogue(A W^T + bias) with A = a_f16_dev [M][K] or,
+ * when x_f32_dev != NULL, A = LayerNorm(x_f32_dev [M][K]; gamma, beta, eps 1e-5) computed in the kernel's prologue.
+ * out_mode as wca_test_gemm; splitk 0 = smallest split with K / splitk <= 1024, groups 0 = chosen; kv_k / kv_v != NULL
+ * (out_mode 0, N = 3 d): columns [d, 3d) go to the caches [M][T_max][d] at position kv_t instead of C. */
+int wca_test_gemm_rows(wca_engine* e, const void* a_f16_dev, const float* x_f32_dev, const float* gamma_dev, const float* beta_dev,
+                       const void* w_f16_dev, const float* bias_dev, void* c_dev, int M, int N, int K, int gelu, int out_mode, int splitk,
+                       int groups, void* kv_k_f16_dev, void* kv_v_f16_dev, int T_max, int kv_t);
 /* diagnostic build of the pipelined 256x256 GEMM that records s_memtime stamps per K tile into dbg_dev
  * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
@@ -302,6 +309,13 @@ int wca_set_fuse_ln(wca_engine* e, int on);
  * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
  * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */
 int wca_set_overlap(wca_engine* e, int on);
+/* Decoder GEMMs on few rows (a greedy-decode step of wca_greedy_decode: M = batch; batch-1 teacher-forced forwards):
+ * fused != 0 (default): for up to 128 rows one few-row kernel per GEMM with the LayerNorm in its prologue, the KV-cache append in its
+ * epilogue and deterministic split-K for K = 4 n_state; 0: separate LayerNorm / GEMM / append launches (the round-1 path,
+ * kept for A/B tests). streams: 1 (default) or 2 = the batch as two half-batches enqueued layer by layer in turn on two streams
+ * (measured on MI355X: the two hardware queues' kernels run back to back rather than concurrently, 3.86 vs 3.90 ms per step).
+ * Token choices are independent of both settings up to fp32 summation order in the split-K GEMM. */
+int wca_set_decode_mode(wca_engine* e, int fused, int streams);
 /* enable/disable per-stage event recording (default off: no extra events on the stream) */
 int wca_set_profiling(wca_engine* e, int on);
 

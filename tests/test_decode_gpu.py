@@ -160,6 +160,35 @@ def test_greedy_decode_vs_oracle(pkg, small):
         assert all(x <= y for x, y in zip(ts, ts[1:]))
 
 
+def test_decode_modes_agree(pkg):
+    """wca_set_decode_mode: the few-row GEMM with LayerNorm prologue / KV append / split-K (fc2: K = 2048 -> 2 workgroups per
+    column group) against the separate-launch path, and the two interleaved half-batches (16 + 4 rows on two streams) against
+    one stream. Same arithmetic except the split-K summation order: the token rows must agree; one / two streams bit for bit."""
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    dims = pkg.ModelDimensions(80, 1500, 512, 8, 2, 51865, 448, 512, 8, 2)
+    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=20)
+    m.load_state_dict(syn.random_state_dict(dims, seed=11))
+    decoding, tok, opts, sup, blank = _setup(pkg, dims)
+    B, sample_len = 20, 10
+    pcm = torch.from_numpy(np.stack([syn.synth_audio(40 + b, n_samples=32000) for b in range(B)])).cuda()
+    ns = np.full(B, 32000, np.int32)
+    initial = list(tok.sot_sequence)
+    out = {}
+    for mode in ((False, 1), (True, 1), (True, 2)):
+        m.set_decode_mode(*mode)
+        out[mode] = m.greedy_decode(None, pcm, ns, initial, sup, blank, sample_len=sample_len, eot=tok.eot,
+                                    timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50,
+                                    no_speech=tok.no_speech) + (m.last_no_speech_prob.copy(),)
+    m.set_decode_mode(True, 1)
+    t1, n1, lp1, ns1 = out[(True, 1)]
+    t2, n2, lp2, ns2 = out[(True, 2)]
+    assert np.array_equal(t1, t2) and np.array_equal(n1, n2) and np.array_equal(lp1, lp2) and np.array_equal(ns1, ns2)
+    t0, n0, lp0, ns0 = out[(False, 1)]
+    assert np.array_equal(t0, t1) and np.array_equal(n0, n1)
+    np.testing.assert_allclose(lp0, lp1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ns0, ns1, rtol=1e-4, atol=1e-7)
+
+
 def test_decode_api_and_encoder_reuse(pkg, small, fake_vocab):
     """whisper.decode mirror + the alignment that follows re-uses the encoder state (pcm=None) and gives the same
     jump frames as a from-scratch align_batch on the same tokens."""

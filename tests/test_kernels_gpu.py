@@ -223,6 +223,95 @@ def test_gemm_residual_layernorm_rejects_unsupported_shapes(eng, lib, wca):
             wca._lib.check(lib.wca_test_gemm_ln(eng._h, _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), M, N, K, 1))
 
 
+# ------------------------------------------------------------------------------- few-row GEMM (decode steps)
+def _rows_gemm(eng, lib, wca, a, x, gamma, beta, w, bias, M, N, K, gelu, out_mode, splitk=0, groups=0, c0=None, kv=None, T_max=0, t=0):
+    if out_mode == 0:
+        c = torch.full((M, N), float("nan"), dtype=torch.float16, device="cuda")
+    elif out_mode == 1:
+        c = torch.full((M, N), float("nan"), device="cuda")
+    else:
+        c = c0.clone()
+    kk, kv_ = (kv if kv is not None else (None, None))
+    wca._lib.check(lib.wca_test_gemm_rows(eng._h, _vp(a), _vp(x), _vp(gamma), _vp(beta), _vp(w), _vp(bias), _vp(c), M, N, K,
+                                          gelu, out_mode, splitk, groups, _vp(kk), _vp(kv_), T_max, t))
+    torch.cuda.synchronize()
+    return c
+
+
+@pytest.mark.parametrize("M,N,K,gelu,out_mode", [(64, 3072, 1024, 0, 0), (64, 4096, 1024, 1, 0), (64, 1024, 1024, 0, 2), (64, 1024, 4096, 0, 2),
+                                                 (37, 1024, 4096, 0, 2), (1, 1024, 1024, 0, 0), (69, 3072, 1024, 0, 0), (128, 1024, 4096, 0, 2),
+                                                 (64, 1280, 1280, 0, 2), (64, 1280, 5120, 0, 2), (33, 1536, 384, 1, 0), (64, 51865, 1024, 0, 1),
+                                                 (5, 1000, 768, 0, 1)])
+def test_gemm_rows_matches_fp32(eng, lib, wca, M, N, K, gelu, out_mode):
+    """The few-row kernel on f16 rows (A_MODE 0) against fp32 torch: every decoder shape of a greedy step (medium and
+    large widths: split-K 1, 2, 4, 5), ragged M / N, M > 64 (two row blocks), the vocabulary projection (13 column groups per
+    workgroup through the register ring)."""
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    c0 = torch.randn(M, N, generator=g, device="cuda") * 2.0
+    c = _rows_gemm(eng, lib, wca, a, None, None, None, w, bias, M, N, K, gelu, out_mode, c0=c0)
+    ref = a.float() @ w.float().T + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    if out_mode == 2:
+        ref = ref + c0
+    tol = 2e-3 if out_mode else 6e-3
+    err = float(((c.float() - ref).abs() / (1.0 + ref.abs())).max())
+    assert err <= tol, err
+    # deterministic: a second launch (split-K partials summed by whichever workgroup arrives last) gives the same bits
+    c2 = _rows_gemm(eng, lib, wca, a, None, None, None, w, bias, M, N, K, gelu, out_mode, c0=c0)
+    assert torch.equal(c, c2)
+
+
+@pytest.mark.parametrize("M,N,K,gelu,out_mode", [(64, 3072, 1024, 0, 0), (64, 4096, 1024, 1, 0), (64, 1024, 1024, 0, 0), (1, 1024, 1024, 0, 0),
+                                                 (50, 2304, 768, 0, 0), (64, 2048, 512, 1, 0), (64, 51865, 1024, 0, 1), (69, 3072, 1024, 0, 0)])
+def test_gemm_rows_layernorm_prologue_is_bit_identical_to_separate_launches(eng, lib, wca, M, N, K, gelu, out_mode):
+    """A_MODE 1: LayerNorm(x) computed in the GEMM's prologue. The prologue repeats the arithmetic of the LayerNorm kernel and
+    the MFMA / cross-wave summation order of the f16-row path, so the result must equal LayerNorm kernel + few-row GEMM on
+    its output BIT FOR BIT (and fp32 torch within f16 operand rounding)."""
+    g = torch.Generator(device="cuda").manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g, device="cuda") * 2.0
+    x[0] += 100.0
+    gamma = torch.rand(K, generator=g, device="cuda") + 0.5
+    beta = torch.randn(K, generator=g, device="cuda") * 0.3
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    fused = _rows_gemm(eng, lib, wca, None, x, gamma, beta, w, bias, M, N, K, gelu, out_mode)
+    xn = torch.empty(M, K, dtype=torch.float16, device="cuda")
+    wca._lib.check(lib.wca_test_layernorm(eng._h, _vp(x), _vp(gamma), _vp(beta), _vp(xn), M, K))
+    torch.cuda.synchronize()
+    sep = _rows_gemm(eng, lib, wca, xn, None, None, None, w, bias, M, N, K, gelu, out_mode)
+    assert torch.equal(fused, sep)
+    ref = torch.nn.functional.layer_norm(x, (K,), gamma, beta, 1e-5) @ w.float().T + bias
+    if gelu:
+        ref = torch.nn.functional.gelu(ref)
+    err = float(((fused.float() - ref).abs() / (1.0 + ref.abs())).max())
+    assert err <= 8e-3, err
+
+
+def test_gemm_rows_kv_append_routing(eng, lib, wca):
+    """QKV projection of a decode step: q columns to C, k / v columns straight into the caches [B][T_max][d] at position t."""
+    B, d, T_max, t = 48, 1024, 40, 17
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(B, d, generator=g, device="cuda")
+    gamma = torch.rand(d, generator=g, device="cuda") + 0.5
+    beta = torch.randn(d, generator=g, device="cuda") * 0.1
+    w = (torch.randn(3 * d, d, generator=g, device="cuda") * 0.05).half()
+    bias = torch.randn(3 * d, generator=g, device="cuda")
+    plain = _rows_gemm(eng, lib, wca, None, x, gamma, beta, w, bias, B, 3 * d, d, 0, 0)
+    kc = torch.full((B, T_max, d), 7.0, dtype=torch.float16, device="cuda")
+    vc = torch.full((B, T_max, d), 9.0, dtype=torch.float16, device="cuda")
+    routed = _rows_gemm(eng, lib, wca, None, x, gamma, beta, w, bias, B, 3 * d, d, 0, 0, kv=(kc, vc), T_max=T_max, t=t)
+    assert torch.equal(routed[:, :d], plain[:, :d])
+    assert torch.equal(kc[:, t], plain[:, d:2 * d]) and torch.equal(vc[:, t], plain[:, 2 * d:])
+    keep = torch.ones(T_max, dtype=torch.bool)
+    keep[t] = False
+    assert bool((kc[:, keep] == 7.0).all()) and bool((vc[:, keep] == 9.0).all())   # nothing else touched
+    assert bool(torch.isnan(routed[:, d:].float()).all())                             # the k / v columns of C are not written
+
+
 # ------------------------------------------------------------------------------- attention
 def _attn_ref(q, k, v, H, causal):
     B, nq, d = q.shape

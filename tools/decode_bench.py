@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the greedy ASR pre-pass (wca_greedy_decode) at whisper-medium dims, random weights: per-step cost of the
-KV-cached decode loop beside the encoder it shares with the alignment. Random weights never emit EOT on their own,
-so the loop runs its full sample_len; usage: decode_bench.py [batch] [sample_len]."""
+"""Greedy ASR pre-pass (wca_greedy_decode) at the bench's model / batch: ms per autoregressive step with the encoder state
+already queued (wca_encode_batch), so that only the KV-cached loop is timed.  usage: decode_bench.py [B] [sample_len] [rounds]"""
 import importlib
 import os
 import sys
@@ -13,65 +12,36 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 wca = importlib.import_module("whisper-char-alignment_amd")
 syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
-decoding = importlib.import_module("whisper-char-alignment_amd.decoding")
-tokmod = importlib.import_module("whisper-char-alignment_amd.tokenizer")
+tok_mod = importlib.import_module("whisper-char-alignment_amd.tokenizer")
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-S = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-dims = wca.dims_for("medium")
-m = wca.WhisperAMD(dims, max_batch=B).load_state_dict(syn.random_state_dict(dims, seed=0))
-tok = tokmod.get_tokenizer(True, language="en", task="transcribe")
-sup, blank = decoding.filter_masks(tok, decoding.DecodingOptions(language="en"), dims.n_vocab)
-pcm = torch.from_numpy(np.stack([syn.synth_audio(b) for b in range(B)])).cuda()
-ns = [160000] * B
-
-
-def run(sample_len):
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    m.greedy_decode(None, pcm, ns, list(tok.sot_sequence), sup, blank, sample_len=sample_len, eot=tok.eot,
-                    timestamp_begin=tok.timestamp_begin)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) * 1e3
-
-
-run(4)
-t_short = min(run(4) for _ in range(2))
-t_long = min(run(S) for _ in range(2))
-per_step = (t_long - t_short) / (S - 4)
-print("B=%d: encoder+cross-KV+%d-step loop %.1f ms; %d-step loop %.1f ms -> %.3f ms per decode step (%.1f us per utterance-step)" %
-      (B, 4, t_short, S, t_long, per_step, per_step * 1e3 / B), flush=True)
-
-# ---- the whole ASR-teacher flow (infer_ali.py --teacher asr): encode -> greedy decode -> alignment re-using the encoder
-# state, serial vs two-deep pipeline (next batch encoded on stream 1 while this one is decoded / aligned on stream 2)
-retok = importlib.import_module("whisper-char-alignment_amd.retokenize")
-row = [*tok.sot_sequence, tok.no_timestamps, *retok.encode(syn.synth_text(0, 64), tok, "char"), tok.eot]
-tokens = torch.tensor([row] * B, dtype=torch.int64, device="cuda")
-o = m.make_opts(aggregation="topk", topk=10, sot_len=len(tok.sot_sequence), medfilt_width=3)
-kw = dict(sample_len=S, eot=tok.eot, timestamp_begin=tok.timestamp_begin)
-NB = 4
-
-
-def serial():
-    for _ in range(NB):
-        m.greedy_decode(None, pcm, ns, list(tok.sot_sequence), sup, blank, **kw)
-        m.align_batch(None, None, tokens, [len(row)] * B, [500] * B, o)
-
-
-def pipelined():
+sample_len = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+model_name = os.environ.get("WCA_MODEL", "medium")
+dims = wca.dims_for(model_name)
+m = wca.WhisperAMD(dims, max_batch=B)
+m.load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
+tok = tok_mod.get_tokenizer(True, language="en")
+initial = list(tok.sot_sequence)
+sup = np.zeros(dims.n_vocab, np.uint8)
+sup[tok.eot] = 1  # never finish early: every round runs exactly sample_len steps
+sup[tok.no_timestamps] = 1
+pcm = torch.from_numpy(np.stack([syn.synth_audio(b, 160000) for b in range(B)])).cuda()
+ns = np.full(B, 160000, np.int32)
+kw = dict(sample_len=sample_len, eot=tok.eot, timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True,
+          max_initial_timestamp_index=50)
+modes = [(bool(int(x.split(":")[0])), int(x.split(":")[1])) for x in os.environ.get("WCA_DEC_MODES", "0:1,0:2,1:1,1:2").split(",")]
+for mode in modes:
+  m.set_decode_mode(*mode)
+  print("decode mode: fused=%s streams=%d" % mode, flush=True)
+  for r in range(rounds + 1):
     m.encode_batch(pcm=pcm, n_samples=ns)
-    for k in range(NB):
-        if k + 1 < NB:
-            m.encode_batch(pcm=pcm, n_samples=ns)
-        m.greedy_decode(None, None, None, list(tok.sot_sequence), sup, blank, batch=B, **kw)
-        m.align_batch(None, None, tokens, [len(row)] * B, [500] * B, o)
-
-
-for name, fn in (("serial", serial), ("pipelined", pipelined)):
-    fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fn()
+    toks, n_tok, lp = m.greedy_decode(None, None, None, initial, sup, None, batch=B, **kw)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / NB
-    print("ASR-teacher flow, %s: %.1f ms per batch of %d (%d decode steps) = %.0f utt/s" % (name, dt * 1e3, B, S, B / dt), flush=True)
+    dt = time.perf_counter() - t0
+    steps = len(initial) - 1 + sample_len  # the prompt is fed position by position through the same step
+    print("  round %d: B=%d %s  %.1f ms for %d sampled tokens (+%d prompt positions)  -> %.3f ms per position, %.0f utt/s decode-only"
+          % (r, B, model_name, dt * 1e3, sample_len, len(initial), dt * 1e3 / steps, B / dt), flush=True)
+  print("  tokens[0][:12] =", toks[0][:12].tolist(), " n_tok[0] =", int(n_tok[0]))

@@ -85,6 +85,8 @@ SIGNATURES = {
     "wca_last_kernel_ms": (_i, [_vp, _i, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wca_set_overlap": (_i, [_vp, _i]),
     "wca_set_fuse_ln": (_i, [_vp, _i]),
+    "wca_set_decode_mode": (_i, [_vp, _i, _i]),
+    "wca_test_gemm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
 }
 
 _lib = None

@@ -13,6 +13,7 @@
 //   decode    f16 self-attention K/V cache [L][2][B][T_max][d], int32 token rows, fp32 logits [B][n_vocab]
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -50,6 +51,13 @@ int fail(int code, const char* fmt, ...) {
 
 constexpr int N_FRAMES = 3000, N_CTX = 1500, MAX_TOK = 448, N_BIN = 201, N_FFT = 400;
 constexpr int META_SLOTS = 16;
+constexpr int DEC_ROWS_MAX = 128;  // decoder GEMMs on at most this many rows take the few-row kernel (gemm_rows.hip)
+
+#define WCA_TRY(expr)          \
+  do {                         \
+    const int _rc = (expr);    \
+    if (_rc != WCA_OK) return _rc; \
+  } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -105,7 +113,10 @@ struct wca_engine {
   hipStream_t stream = nullptr;      // phase 1 (log-mel, encoder, cross-K/V) and every non-batched entry point
   hipStream_t own_stream = nullptr;
   hipStream_t stream2 = nullptr;     // phase 2 of wca_align_batch (decoder, post-processing, DTW, D2H): overlaps the next batch's phase 1
+  hipStream_t stream3 = nullptr;     // second half-batch of the greedy decode loop (wca_greedy_decode): its latency-bound small
+                                     // kernels run under the other half's HBM-bound cross-attention
   hipEvent_t ev_kv[2] = {};          // cross-K/V of batch slot ready (recorded on `stream`)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // stream2 -> stream3 fork / join of the decode loop
   bool finalized = false;
   bool have_filters = false;
   bool profiling = false;
@@ -150,6 +161,9 @@ struct wca_engine {
   int meta_slot = 0;
   unsigned long long* ln_stats = nullptr;  // out_mode 3 GEMMs: per-tile row statistics [n_state/256][B*1500 padded to 256]
   unsigned* ln_cnt = nullptr;              // ... and per-panel arrival counters (zeroed by launch_gemm)
+  float* sk_part[2] = {nullptr, nullptr};  // split-K workspaces of the few-row GEMM (one per decode stream) and their
+  unsigned* sk_cnt[2] = {nullptr, nullptr};  // arrival counters (zero at creation, self-cleaning)
+  size_t sk_floats = 0, sk_tiles = 0;
   int n_cu = 0;
   int* err_dev = nullptr;    // device flag raised by kernels: bit 0 token id outside the vocabulary, bit 1 LayerNorm hand-off timeout
   int* err_host = nullptr;   // pinned: read back by the synchronous entry points
@@ -180,6 +194,9 @@ struct wca_engine {
   bool kev_set[WCA_N_SITES][32] = {};   // which (site, layer) pairs the last encoder run recorded
   bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
+  bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= 256 rows (wca_set_decode_mode)
+  int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
+                             // back to back, not concurrently -- 3.86 vs 3.90 ms per step -- so one stream is the default)
   bool ev_valid = false;
   float stage_ms[8] = {};
 };
@@ -290,6 +307,16 @@ size_t layout_arena(wca_engine* e, char* base) {
     e->ln_stats = carve<unsigned long long>(cur, (d / 256 + 1) * mpad);
     e->ln_cnt = carve<unsigned>(cur, mpad / 256 + 16, 256);
   }
+  {
+    // few-row GEMM, split-K (K > 1024: fc2; every K of the 1280-wide model): up to ROWS_MAX rows, N = n_text_state columns
+    const int s_max = std::max(std::max(gemm_rows_pick_splitk((int)dt), gemm_rows_pick_splitk((int)(4 * dt))), 1);
+    e->sk_tiles = (size_t)(DEC_ROWS_MAX / 64) * ((dt + 15) / 16);
+    e->sk_floats = e->sk_tiles * s_max * 64 * 16;
+    for (int i = 0; i < 2; ++i) {
+      e->sk_part[i] = carve<float>(cur, e->sk_floats);
+      e->sk_cnt[i] = carve<unsigned>(cur, e->sk_tiles + 16, 256);
+    }
+  }
   return (size_t)(cur - base) + 4096;
 }
 
@@ -310,6 +337,58 @@ hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ld
   g.out_mode = out_mode;
   g.site = site;
   return launch_gemm(g, s);
+}
+
+// One GEMM of the decoder on few rows (a greedy-decode step: M = batch; batch-1 teacher-forced forwards: M = n tokens).
+// xln != nullptr: the A operand is LayerNorm(xln rows; ln_g, ln_b). kv_k != nullptr (QKV projection of a decode step, N = 3 d):
+// the k / v columns go to the self-attention cache at position kv_t. M <= DEC_ROWS_MAX and a shape the few-row kernel takes:
+// one launch (gemm_rows.hip); otherwise the separate LayerNorm / GEMM / kv_append launches.
+int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, const float* xln, const float* ln_g, const float* ln_b,
+             half_t* xn_scratch, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M, int N, int K, int gelu, int out_mode,
+             int site, half_t* kv_k = nullptr, half_t* kv_v = nullptr, int T_max = 0, int kv_t = 0) {
+  const bool ln = xln != nullptr;
+  const int sk = gemm_rows_pick_splitk(K);
+  const bool fits = sk <= 1 || (kv_k == nullptr && (size_t)((M + 63) / 64) * ((N + 15) / 16) <= e->sk_tiles &&
+                                gemm_rows_workspace_bytes(M, N, sk) <= e->sk_floats * sizeof(float));
+  if (e->dec_fused && M <= DEC_ROWS_MAX && gemm_rows_supported(M, N, K, ln) && fits) {
+    GemmArgs g{};
+    g.A = A;
+    g.lda = lda;
+    g.A32 = xln;
+    g.lda32 = K;
+    g.ln_gamma = ln_g;
+    g.ln_beta = ln_b;
+    g.ln_eps = 1e-5f;
+    g.W = W;
+    g.ldw = ldw;
+    g.bias = bias;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = N;
+    g.K = K;
+    g.gelu = gelu;
+    g.out_mode = out_mode;
+    g.site = site;
+    g.splitk = sk;
+    g.sk_part = e->sk_part[ws];
+    g.sk_cnt = e->sk_cnt[ws];
+    g.kv_k = kv_k;
+    g.kv_v = kv_v;
+    g.kv_bs = (long)T_max * K;
+    g.kv_t = kv_t;
+    g.kv_d = kv_k ? N / 3 : 0;
+    HIPCHK(launch_gemm_rows(g, s));
+    return WCA_OK;
+  }
+  if (ln) {
+    HIPCHK(launch_layernorm_f16(xln, ln_g, ln_b, xn_scratch, M, K, 1e-5f, s));
+    A = xn_scratch;
+    lda = K;
+  }
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, C, ldc, M, N, K, gelu, out_mode, site));
+  if (kv_k) HIPCHK(launch_kv_append(reinterpret_cast<const half_t*>(C), kv_k, kv_v, M, T_max, kv_t, N / 3, s));
+  return WCA_OK;
 }
 
 // x (f32 residual stream, [M][N]) += A W^T + bias, then xn (f16) = LayerNorm(x) with (gamma, beta): ONE kernel where the
@@ -562,8 +641,7 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->dec[li];
-    HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, M, 3 * dt, dt, 0, 0, 2));
+    WCA_TRY(dec_gemm(e, s, 0, nullptr, 0, e->xd, l.ln1_g, l.ln1_b, e->xdn, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, M, 3 * dt, dt, 0, 0, 2));
     {
       AttnArgs a{};
       a.Q = e->qkv_d;
@@ -582,9 +660,8 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
       a.causal = 1;
       HIPCHK(launch_attention(a, s));
     }
-    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, M, dt, dt, 0, 2, 2));
-    HIPCHK(launch_layernorm_f16(e->xd, l.lnc_g, l.lnc_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, M, dt, dt, 0, 0, 2));
+    WCA_TRY(dec_gemm(e, s, 0, e->att_d, dt, nullptr, nullptr, nullptr, nullptr, l.out_w, dt, l.out_b, e->xd, dt, M, dt, dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, 0, nullptr, 0, e->xd, l.lnc_g, l.lnc_b, e->xdn, l.cq_w, dt, l.cq_b, e->q_d, dt, M, dt, dt, 0, 0, 2));
     {
       AttnArgs a{};
       a.Q = e->q_d;
@@ -612,45 +689,56 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
     }
     // the last layer's cross-attention logits are captured by now: without logits nothing downstream is read
     if (li == L - 1 && !logits_out) break;
-    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2, 2));
-    HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0, 2));
-    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, M, dt, 4 * dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, 0, e->att_d, dt, nullptr, nullptr, nullptr, nullptr, l.co_w, dt, l.co_b, e->xd, dt, M, dt, dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, 0, nullptr, 0, e->xd, l.ln2_g, l.ln2_b, e->xdn, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, M, 4 * dt, dt, 1, 0, 2));
+    WCA_TRY(dec_gemm(e, s, 0, e->hid_d, 4 * dt, nullptr, nullptr, nullptr, nullptr, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, M, dt, 4 * dt, 0, 2, 2));
   }
   if (logits_out) {
-    HIPCHK(launch_layernorm_f16(e->xd, e->lnf_g, e->lnf_b, e->xdn, M, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, logits_out, D.n_vocab, M, D.n_vocab, dt, 0, 1, 3));
+    WCA_TRY(dec_gemm(e, s, 0, nullptr, 0, e->xd, e->lnf_g, e->lnf_b, e->xdn, e->tok_emb, dt, nullptr, logits_out, D.n_vocab, M, D.n_vocab, dt, 0, 1, 3));
   }
   return WCA_OK;
 }
 
-// One autoregressive step of the greedy ASR pre-pass for B rows: position t of every row (token tokens[b][t]) through
-// the decoder with the self-attention K/V cache (positions 0..t), cross-attention over this batch's cross-K/V; logits
-// of that position -> e->dec_logits. Same kernels as run_decoder with one query row per utterance.
-int run_decode_step(wca_engine* e, hipStream_t s, const half_t* kvbuf, const int* tokens, int B, int t, int T_max, bool want_logits) {
+// One autoregressive step of the greedy ASR pre-pass for rows [b0, b0 + B) of the batch: position t of every row (token
+// tokens[b][t]) through the decoder with the self-attention K/V cache (positions 0..t), cross-attention over this batch's
+// cross-K/V; logits of that position -> e->dec_logits. `ws` = which split-K workspace (one per decode stream). Eight
+// launches per layer: [LN1 + QKV + cache append], self-attention, [out-projection + residual], [LNc + cross query],
+// cross-attention, [cross out + residual], [LN2 + fc1 + GELU], [fc2 + residual, split-K].
+// phase: -1 = embedding only, li in [0, L) = decoder layer li only, L = final LayerNorm + logits only, -2 = the whole step.
+// The two half-batches of wca_greedy_decode are enqueued layer by layer in turn (the queues are served in the order their
+// packets arrive: coarse enqueueing gives coarse alternation and no overlap).
+int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, const int* tokens, int b0, int B, int B_all, int t, int T_max,
+                    bool want_logits, int phase = -2) {
   const wca_model_dims& D = e->dims;
   const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
   half_t* cache = (half_t*)e->dec_cache.p;
-  const size_t plane = (size_t)B * T_max * dt;  // one layer's K (or V) cache
-  HIPCHK(launch_embed_step(tokens, T_max, t, e->tok_emb, e->dec_pos, e->xd, B, dt, D.n_vocab, s));
+  const size_t plane = (size_t)B_all * T_max * dt;  // one layer's K (or V) cache
+  float* xd = e->xd + (size_t)b0 * dt;
+  half_t* xdn = e->xdn + (size_t)b0 * dt;
+  half_t* qkv_d = e->qkv_d + (size_t)b0 * 3 * dt;
+  half_t* att_d = e->att_d + (size_t)b0 * dt;
+  half_t* q_d = e->q_d + (size_t)b0 * dt;
+  half_t* hid_d = e->hid_d + (size_t)b0 * 4 * dt;
+  const half_t* kvb = kvbuf + (size_t)b0 * N_CTX * L * 2 * dt;
+  if (phase == -2 || phase == -1)
+    HIPCHK(launch_embed_step(tokens + (size_t)b0 * T_max, T_max, t, e->tok_emb, e->dec_pos, xd, B, dt, D.n_vocab, s));
   for (int li = 0; li < L; ++li) {
+    if (phase != -2 && phase != li) continue;
     const LayerW& l = e->dec[li];
-    half_t* kc = cache + (size_t)(2 * li) * plane;
+    half_t* kc = cache + (size_t)(2 * li) * plane + (size_t)b0 * T_max * dt;
     half_t* vc = kc + plane;
-    HIPCHK(launch_layernorm_f16(e->xd, l.ln1_g, l.ln1_b, e->xdn, B, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.qkv_w, dt, l.qkv_b, e->qkv_d, 3 * dt, B, 3 * dt, dt, 0, 0, 2));
-    HIPCHK(launch_kv_append(e->qkv_d, kc, vc, B, T_max, t, dt, s));
+    WCA_TRY(dec_gemm(e, s, ws, nullptr, 0, xd, l.ln1_g, l.ln1_b, xdn, l.qkv_w, dt, l.qkv_b, qkv_d, 3 * dt, B, 3 * dt, dt, 0, 0, 2, kc, vc, T_max, t));
     {
       AttnArgs a{};
-      a.Q = e->qkv_d;
+      a.Q = qkv_d;
       a.q_bs = 3 * dt;
       a.q_rs = 3 * dt;
       a.K = kc;
       a.V = vc;
       a.k_bs = a.v_bs = (long)T_max * dt;
       a.k_rs = a.v_rs = dt;
-      a.O = e->att_d;
+      a.O = att_d;
       a.o_bs = dt;
       a.o_rs = dt;
       a.nq = 1;
@@ -661,19 +749,18 @@ int run_decode_step(wca_engine* e, hipStream_t s, const half_t* kvbuf, const int
       a.causal = 0;
       HIPCHK(launch_attention(a, s));
     }
-    HIPCHK(gemm(s, e->att_d, dt, l.out_w, dt, l.out_b, e->xd, dt, B, dt, dt, 0, 2, 2));
-    HIPCHK(launch_layernorm_f16(e->xd, l.lnc_g, l.lnc_b, e->xdn, B, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.cq_w, dt, l.cq_b, e->q_d, dt, B, dt, dt, 0, 0, 2));
+    WCA_TRY(dec_gemm(e, s, ws, att_d, dt, nullptr, nullptr, nullptr, nullptr, l.out_w, dt, l.out_b, xd, dt, B, dt, dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, ws, nullptr, 0, xd, l.lnc_g, l.lnc_b, xdn, l.cq_w, dt, l.cq_b, q_d, dt, B, dt, dt, 0, 0, 2));
     {
       AttnArgs a{};
-      a.Q = e->q_d;
+      a.Q = q_d;
       a.q_bs = dt;
       a.q_rs = dt;
-      a.K = kvbuf + (size_t)(2 * li) * dt;
-      a.V = kvbuf + (size_t)(2 * li + 1) * dt;
+      a.K = kvb + (size_t)(2 * li) * dt;
+      a.V = kvb + (size_t)(2 * li + 1) * dt;
       a.k_bs = a.v_bs = (long)N_CTX * L * 2 * dt;
       a.k_rs = a.v_rs = L * 2 * dt;
-      a.O = e->att_d;
+      a.O = att_d;
       a.o_bs = dt;
       a.o_rs = dt;
       a.nq = 1;
@@ -684,15 +771,13 @@ int run_decode_step(wca_engine* e, hipStream_t s, const half_t* kvbuf, const int
       a.causal = 0;
       HIPCHK(launch_attention(a, s));
     }
-    HIPCHK(gemm(s, e->att_d, dt, l.co_w, dt, l.co_b, e->xd, dt, B, dt, dt, 0, 2, 2));
-    HIPCHK(launch_layernorm_f16(e->xd, l.ln2_g, l.ln2_b, e->xdn, B, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, l.fc1_w, dt, l.fc1_b, e->hid_d, 4 * dt, B, 4 * dt, dt, 1, 0, 2));
-    HIPCHK(gemm(s, e->hid_d, 4 * dt, l.fc2_w, 4 * dt, l.fc2_b, e->xd, dt, B, dt, 4 * dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, ws, att_d, dt, nullptr, nullptr, nullptr, nullptr, l.co_w, dt, l.co_b, xd, dt, B, dt, dt, 0, 2, 2));
+    WCA_TRY(dec_gemm(e, s, ws, nullptr, 0, xd, l.ln2_g, l.ln2_b, xdn, l.fc1_w, dt, l.fc1_b, hid_d, 4 * dt, B, 4 * dt, dt, 1, 0, 2));
+    WCA_TRY(dec_gemm(e, s, ws, hid_d, 4 * dt, nullptr, nullptr, nullptr, nullptr, l.fc2_w, 4 * dt, l.fc2_b, xd, dt, B, dt, 4 * dt, 0, 2, 2));
   }
-  if (want_logits) {
-    HIPCHK(launch_layernorm_f16(e->xd, e->lnf_g, e->lnf_b, e->xdn, B, dt, 1e-5f, s));
-    HIPCHK(gemm(s, e->xdn, dt, e->tok_emb, dt, nullptr, e->dec_logits.p, D.n_vocab, B, D.n_vocab, dt, 0, 1, 3));
-  }
+  if (want_logits && (phase == -2 || phase == L))
+    WCA_TRY(dec_gemm(e, s, ws, nullptr, 0, xd, e->lnf_g, e->lnf_b, xdn, e->tok_emb, dt, nullptr, (float*)e->dec_logits.p + (size_t)b0 * D.n_vocab,
+                     D.n_vocab, B, D.n_vocab, dt, 0, 1, 3));
   return WCA_OK;
 }
 
@@ -936,6 +1021,9 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   HIPCHK(hipDeviceGetAttribute(&e->n_cu, hipDeviceAttributeMultiprocessorCount, device_ordinal));
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   e->stream = e->own_stream;
   for (auto& ev : e->ev_kv) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   e->wslab_bytes = layout_weights(e, nullptr);
@@ -1001,6 +1089,9 @@ void wca_engine_destroy(wca_engine* e) {
   }
   for (auto& ev : e->ev_kv)
     if (ev) (void)hipEventDestroy(ev);
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->stream3) (void)hipStreamDestroy(e->stream3);
   if (e->stream2) (void)hipStreamDestroy(e->stream2);
   if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
@@ -1017,6 +1108,15 @@ int wca_engine_synchronize(wca_engine* e) {
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipStreamSynchronize(e->stream2));
+  HIPCHK(hipStreamSynchronize(e->stream3));
+  return WCA_OK;
+}
+
+int wca_set_decode_mode(wca_engine* e, int fused, int streams) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (streams != 1 && streams != 2) return fail(WCA_ERR_INVALID, "streams must be 1 or 2");
+  e->dec_fused = fused != 0;
+  e->dec_streams = streams;
   return WCA_OK;
 }
 
@@ -1811,27 +1911,61 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
   sel.max_initial_timestamp_index = o->max_initial_timestamp_index;
   sel.sum_logprob = sum_lp;
   sel.n_done = n_done;
-  // the prompt is fed one position at a time (it is 3 tokens: sot, language, task); sampling starts after its last token
+  // the prompt is fed one position at a time (it is 3 tokens: sot, language, task); sampling starts after its last token.
+  // The batch is decoded as two half-batches on two streams: a step is ~200 dependent launches of 5-10 us plus one
+  // HBM-bound cross-attention per layer, and the halves are independent, so one half's small kernels run under the other
+  // half's cross-K/V stream. Rows never interact (per-row kernels, per-row cache planes); n_done is an atomic counter.
+  const int n_half = (e->dec_streams == 2 && batch >= 16) ? 2 : 1;
+  const int hb[3] = {0, n_half == 2 ? (batch / 2 + 7) / 8 * 8 : batch, batch};
+  hipStream_t hs[2] = {s2, e->stream3};
+  if (n_half == 2) {
+    HIPCHK(hipEventRecord(e->ev_fork, s2));
+    HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));
+  }
   int steps = 0;
+  const bool dbg_host = std::getenv("WCA_DEC_DEBUG") != nullptr;
+  double host_us = 0.0;
   for (int t = 0; t < T_max - 1; ++t) {
     const bool sample = (t >= n_initial - 1);
     const bool sot_logits = (t == 0 && want_nsp);  // probs_at_sot of DecodingTask._main_loop (sot_index = 0: no prompt)
-    rc = run_decode_step(e, s2, kvbuf, tokens_dev, batch, t, T_max, sample || sot_logits);
-    if (rc) return rc;
-    if (sot_logits) HIPCHK(launch_token_prob((const float*)e->dec_logits.p, V, V, o->no_speech, nsp, batch, s2));
+    const auto h0 = std::chrono::steady_clock::now();
+    for (int phase = -1; phase <= L; ++phase)
+      for (int h = 0; h < n_half; ++h) {
+        rc = run_decode_step(e, hs[h], h, kvbuf, tokens_dev, hb[h], hb[h + 1] - hb[h], batch, t, T_max, sample || sot_logits, phase);
+        if (rc) return rc;
+      }
+    for (int h = 0; h < n_half; ++h) {
+      const int b0 = hb[h], nb = hb[h + 1] - hb[h];
+      if (sot_logits) HIPCHK(launch_token_prob((const float*)e->dec_logits.p + (size_t)b0 * V, V, V, o->no_speech, nsp + b0, nb, hs[h]));
+      if (!sample) continue;
+      DecodeSelectArgs sh = sel;
+      sh.logits = sel.logits + (size_t)b0 * V;
+      sh.tokens = sel.tokens + (size_t)b0 * T_max;
+      sh.sum_logprob = sel.sum_logprob + b0;
+      sh.cur_len = t + 1;
+      HIPCHK(launch_decode_select(sh, nb, hs[h]));
+    }
+    if (dbg_host) host_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h0).count();
     if (!sample) continue;
-    sel.cur_len = t + 1;
-    HIPCHK(launch_decode_select(sel, batch, s2));
     ++steps;
     // whisper's loop ends when every row has produced EOT (checked every 4 steps here: a late stop only costs time,
     // finished rows keep emitting EOT) or after sample_len steps
     if ((steps & 3) == 0 || steps == o->sample_len) {
+      if (n_half == 2) {
+        HIPCHK(hipEventRecord(e->ev_join, e->stream3));
+        HIPCHK(hipStreamWaitEvent(s2, e->ev_join, 0));
+      }
       HIPCHK(hipMemcpyAsync(e->dec_done_host, n_done + t + 1, sizeof(int), hipMemcpyDeviceToHost, s2));
       HIPCHK(hipStreamSynchronize(s2));
       if (e->dec_done_host[0] >= batch) break;
     }
     if (steps >= o->sample_len) break;
   }
+  if (n_half == 2) {
+    HIPCHK(hipEventRecord(e->ev_join, e->stream3));
+    HIPCHK(hipStreamWaitEvent(s2, e->ev_join, 0));
+  }
+  if (dbg_host) fprintf(stderr, "[wca] greedy decode: host enqueue time %.1f us per position (%d halves)\n", host_us / (steps + n_initial - 1), n_half);
   std::vector<int32_t> toks((size_t)batch * T_max);
   HIPCHK(hipMemcpyAsync(toks.data(), tokens_dev, sizeof(int) * toks.size(), hipMemcpyDeviceToHost, s2));
   std::vector<float> lp(2 * (size_t)batch);
@@ -1942,6 +2076,59 @@ int wca_test_gemm_ln(wca_engine* e, const void* a, const void* w, const float* b
   HIPCHK(hipMemcpyAsync(e->err_host, e->err_dev, sizeof(int), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   if (e->err_host[0] & 2) return fail(WCA_ERR_HIP, "LayerNorm statistics hand-off timed out");
+  return WCA_OK;
+}
+
+int wca_test_gemm_rows(wca_engine* e, const void* a_f16, const float* x_f32, const float* gamma, const float* beta, const void* w,
+                       const float* bias, void* c, int M, int N, int K, int gelu, int out_mode, int splitk, int groups, void* kv_k, void* kv_v,
+                       int T_max, int kv_t) {
+  if (!e || !w || !c || (!a_f16 && !x_f32) || (x_f32 && (!gamma || !beta))) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (splitk <= 0) splitk = gemm_rows_pick_splitk(K);
+  if (splitk <= 0) return fail(WCA_ERR_INVALID, "no split of K=%d fits the few-row kernel", K);
+  const size_t tiles = (size_t)((M + 63) / 64) * ((N + 15) / 16);
+  if (splitk > 1) {
+    HIPCHK(e->tmp0.ensure(gemm_rows_workspace_bytes(M, N, splitk)));
+    HIPCHK(e->tmp1.ensure(sizeof(unsigned) * tiles));
+    HIPCHK(hipMemsetAsync(e->tmp1.p, 0, sizeof(unsigned) * tiles, e->stream));
+  }
+  GemmArgs g{};
+  g.A = (const half_t*)a_f16;
+  g.lda = K;
+  g.A32 = x_f32;
+  g.lda32 = K;
+  g.ln_gamma = gamma;
+  g.ln_beta = beta;
+  g.ln_eps = 1e-5f;
+  g.W = (const half_t*)w;
+  g.ldw = K;
+  g.bias = bias;
+  g.C = c;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.gelu = gelu;
+  g.out_mode = out_mode;
+  g.splitk = splitk;
+  g.groups = groups;
+  g.sk_part = (float*)e->tmp0.p;
+  g.sk_cnt = (unsigned*)e->tmp1.p;
+  g.kv_k = (half_t*)kv_k;
+  g.kv_v = (half_t*)kv_v;
+  g.kv_bs = (long)T_max * (N / 3);
+  g.kv_t = kv_t;
+  g.kv_d = kv_k ? N / 3 : 0;
+  HIPCHK(launch_gemm_rows(g, e->stream));
+  if (splitk > 1) {
+    // the counters must be back at zero (self-cleaning): a second launch on the same workspace has to give the same result
+    std::vector<unsigned> cnt(tiles);
+    HIPCHK(hipMemcpyAsync(cnt.data(), e->tmp1.p, sizeof(unsigned) * tiles, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (unsigned v : cnt)
+      if (v != 0) return fail(WCA_ERR_HIP, "split-K arrival counter left at %u", v);
+  }
+  HIPCHK(hipStreamSynchronize(e->stream));
   return WCA_OK;
 }
 

@@ -45,8 +45,25 @@ struct GemmArgs {
   int site;                // 0 generic, 1 encoder block (QKV / out-projection / fc1), 2 decoder, 3 conv stem / cross-KV / logits,
                            // 4 encoder fc2: selects a distinct kernel symbol per call site so rocprofv3 --stats separates them
   int supertile;           // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)
+  // ---- few-row kernel only (gemm_rows.hip, launch_gemm_rows):
+  const float* A32;        // non-null: the A operand is LayerNorm(A32 rows; ln_gamma, ln_beta, ln_eps) computed in the prologue
+  int lda32;               // floats between A32 rows (K == row length)
+  half_t* kv_k;            // non-null (out_mode 0, N == 3 kv_d): columns [kv_d, 2 kv_d) of row m go to kv_k + m * kv_bs + kv_t * kv_d,
+  half_t* kv_v;            // columns [2 kv_d, 3 kv_d) to kv_v + ... (the step's KV-cache append); columns [0, kv_d) to C as usual
+  long kv_bs;              // elements between batch rows of a cache plane (T_max * d)
+  int kv_t, kv_d;
+  float* sk_part;          // split-K workspace (gemm_rows_workspace_bytes) and
+  unsigned* sk_cnt;        // one arrival counter per (64-row block, 16-column group), zero before the first launch (self-cleaning)
+  int splitk;              // workgroups sharing K (0 = chosen by launch_gemm_rows: smallest with K / splitk <= 1024)
+  int groups;              // 16-column groups per workgroup (0 = chosen: grid.x <= 256)
 };
 hipError_t launch_gemm(const GemmArgs& a, hipStream_t s);
+// Few-row GEMM (M <= a few hundred rows: greedy-decode steps, batch-1 decoder forwards) with optional LayerNorm prologue,
+// KV-cache append and deterministic split-K; returns hipErrorInvalidValue for shapes it does not take (gemm_rows_supported)
+hipError_t launch_gemm_rows(const GemmArgs& a, hipStream_t s);
+bool gemm_rows_supported(int M, int N, int K, bool layernorm_a);
+int gemm_rows_pick_splitk(int K);
+size_t gemm_rows_workspace_bytes(int M, int N, int splitk);
 // out_mode 3 (residual + LayerNorm epilogue) is available for this shape on a device with n_cu compute units
 bool gemm_ln_supported(int M, int N, int K, int n_cu);
 

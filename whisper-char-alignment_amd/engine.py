@@ -384,6 +384,11 @@ class WhisperAMD:
         """Phase 2 on its own stream (default) or everything on one stream (clean per-kernel profiles)."""
         _lib.check(self._lib.wca_set_overlap(self._h, 1 if on else 0))
 
+    def set_decode_mode(self, fused=True, streams=1):
+        """Few-row decoder GEMMs fused with LayerNorm / KV append / split-K (default) or separate launches; greedy decode as
+        one stream (default) or two interleaved half-batches."""
+        _lib.check(self._lib.wca_set_decode_mode(self._h, 1 if fused else 0, int(streams)))
+
     def last_stage_ms(self):
         ms = (C.c_float * 8)()
         _lib.check(self._lib.wca_last_stage_ms(self._h, ms))
