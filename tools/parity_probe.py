@@ -60,7 +60,13 @@ for j, u in enumerate(ids):
     _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
     st, en = np.asarray(st), np.asarray(en)
     off = int(np.sum(np.abs(st - rst) > 0.02 + 1e-9) + np.sum(np.abs(en - ren) > 0.02 + 1e-9))
-    print("utt %d: %d boundaries outside one frame" % (u, off), flush=True)
+    # the GPU's selection scores of its top-k heads against the oracle's scores of the same heads
+    _gsel, gsc_sorted = timing.filter_attention(weights_gpu[j][:, :, :len(rows[j])], topk, 1, 1, 0)
+    _oall, o_all = timing_ref.filter_attention(w, w.shape[0] * w.shape[1], 1, 1, 0)
+    o_of = {(l, h): sc for sc, (l, h), _n in o_all}
+    dev = max(abs(sc - o_of[lh]) / abs(o_of[lh]) for sc, lh, _n in gsc_sorted)
+    print("utt %d: %d boundaries outside one frame; selection scores GPU vs oracle (top-%d heads): max rel deviation %.2e"
+          % (u, off, topk, dev), flush=True)
     if off == 0:
         continue
     o_heads = [l * H + h for _s, (l, h), _n in rscores]
