@@ -169,6 +169,13 @@ int wca_dtw_batch_dev(wca_engine* e, const float* matrix_dev, int P, int N, int 
  * filter_attention scores (w_col = w_row = 1); jump_frame_host [L*H][n - sot_len - 1]. */
 int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int F, int sot_len, float* scores_host,
                     int32_t* jump_frame_host);
+/* Strict word-boundary scoring of EVERY head of the preceding wca_probe_heads (probe_oracle.py:83-90 calling
+ * metrics.py:45-72 eval_n1_strict once per head): head hd's predicted end of hypothesis word i is
+ * jump_frame[hd][word_end_row[i]] / 50 s; it is a true positive if an unused reference boundary j with
+ * same_word[i * n_ref + j] != 0 lies within `tolerance` (first such j, the reference's loop order). tp_host [n_heads = L*H];
+ * fp = n_hyp - tp, fn = n_ref - tp. Times are compared in float64 like the host code: tp is the same integer. */
+int wca_probe_strict_tp(wca_engine* e, int n_heads, const int32_t* word_end_row_host, int n_hyp, const double* ref_times_host, int n_ref,
+                        const uint8_t* same_word_host, double tolerance, int32_t* tp_host);
 
 /* Fused per-utterance pipeline for a micro-batch (the north-star hot path).
  * pcm_dev [batch][pcm_stride] f32 (NULL: re-use the encoder state of the preceding wca_greedy_decode of this

@@ -214,6 +214,39 @@ def test_probe_heads_matches_per_head_force_align(wca):
             assert np.array_equal(jumps[l * H + h], tj[jm]), (l, h)
 
 
+def test_probe_strict_scoring_on_device_equals_host_loop(wca):
+    """wca_probe_strict_tp == metrics.eval_n1_strict (golden-pinned to the reference's metrics.py:45-72) for every head:
+    repeated words (the `used` set), reference boundaries exactly `tolerance` away (float64 comparison), more / fewer
+    reference words than hypothesis words, no match at all."""
+    probe, metrics = _m("probe_oracle"), _m("metrics")
+    g = torch.Generator().manual_seed(21)
+    L, H, n, F = 3, 4, 44, 260
+    w = torch.softmax(torch.randn(L, H, n, F, generator=g) * 4, -1).cuda()
+    eng = _m("engine").default_engine(0)
+    scores, jumps = probe.probe_heads(eng, w, 3)
+    N = n - 3 - 1
+    rng = np.random.default_rng(4)
+    hyp_words = ["the", "cat", "the", "dog", "The,", "cat", "sat", "the", "end"]
+    cuts = np.sort(rng.choice(np.arange(1, N), size=len(hyp_words) - 1, replace=False))
+    wb = np.concatenate([[0], cuts, [N]])          # word i covers token rows wb[i] .. wb[i+1]-1; its end boundary is row wb[i+1]
+    wb_end = np.minimum(wb[1:], N - 1)
+    for case, ref_words in enumerate((hyp_words, hyp_words[:-2], hyp_words + ["extra", "the"], ["none"] * 5)):
+        # reference boundaries: some head's predictions shifted by exactly one tolerance, a little more, or far away
+        base = (jumps[case % (L * H)] / 50.0)[wb_end]
+        shifts = np.array([0.0, 0.02, -0.02, 0.021, 0.5, -0.019, 0.02, 0.0, 1.0, 0.0, 0.02])
+        ends = np.array([base[min(j, len(base) - 1)] + shifts[j % len(shifts)] for j in range(len(ref_words))], dtype=np.float64)
+        for tol in (0.02, 0.05, 0.0):
+            tp = probe.probe_strict_tp(eng, L * H, wb_end, ends, ref_words, hyp_words, tol)
+            for hd in range(L * H):
+                ends_hat = (jumps[hd] / 50.0)[wb_end]
+                rtp, rfp, rfn = metrics.eval_n1_strict(ends, ends_hat, ref_words, hyp_words, tol)
+                assert tp[hd] == rtp, (case, tol, hd, int(tp[hd]), rtp)
+            f1 = probe.strict_f1(tp, len(hyp_words), len(ref_words))
+            for hd in range(L * H):
+                t = int(tp[hd])
+                assert f1[hd] == metrics.get_seg_metrics(t, t, len(hyp_words), len(ref_words))[2]
+
+
 def test_probe_oracle_cli(corpus):
     root, scp = corpus
     probe = _m("probe_oracle")

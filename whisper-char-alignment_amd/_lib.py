@@ -86,6 +86,7 @@ SIGNATURES = {
     "wca_set_overlap": (_i, [_vp, _i]),
     "wca_set_fuse_ln": (_i, [_vp, _i]),
     "wca_set_decode_mode": (_i, [_vp, _i, _i]),
+    "wca_probe_strict_tp": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_double, _vp]),
     "wca_test_gemm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
 }
 

@@ -170,6 +170,8 @@ struct wca_engine {
 
   // ---- run-time sized buffers
   GrowBuf cap, wws, colnorm, scores, sel, selsc, matrix, trace, path, pathlen, jump, tmp0, tmp1;
+  GrowBuf probe_jump;          // the last wca_probe_heads' jump frames [LH][N], kept on the device for wca_probe_strict_tp
+  int probe_LH = 0, probe_N = 0;
   // greedy ASR pre-pass (wca_greedy_decode): self-attention K/V cache [L][2][B][T_max][d], token rows, masks, logits
   GrowBuf dec_cache, dec_tokens, dec_masks, dec_logits, dec_state;
   int* dec_done_host = nullptr;  // pinned: completion counter read back while the loop runs
@@ -1076,6 +1078,7 @@ void wca_engine_destroy(wca_engine* e) {
   e->dec_masks.release();
   e->dec_logits.release();
   e->dec_state.release();
+  e->probe_jump.release();
   for (int i = 0; i < 2; ++i) {
     if (e->res_host[i]) (void)hipHostFree(e->res_host[i]);
     if (e->res_ev[i]) (void)hipEventDestroy(e->res_ev[i]);
@@ -1586,6 +1589,36 @@ int wca_probe_heads(wca_engine* e, const float* ws_dev, int L, int H, int n, int
   HIPCHK(launch_dtw(dg, e->stream));
   HIPCHK(hipMemcpyAsync(jump_frame_host, e->jump.p, sizeof(int) * (size_t)LH * N, hipMemcpyDeviceToHost, e->stream));
   if (scores_host) HIPCHK(hipMemcpyAsync(scores_host, e->scores.p, sizeof(float) * LH, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e->probe_jump.ensure(sizeof(int) * (size_t)LH * N));
+  HIPCHK(hipMemcpyAsync(e->probe_jump.p, e->jump.p, sizeof(int) * (size_t)LH * N, hipMemcpyDeviceToDevice, e->stream));
+  e->probe_LH = LH;
+  e->probe_N = N;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
+int wca_probe_strict_tp(wca_engine* e, int n_heads, const int32_t* word_end_row_host, int n_hyp, const double* ref_times_host, int n_ref,
+                        const uint8_t* same_word_host, double tolerance, int32_t* tp_host) {
+  if (!e || !tp_host || (n_hyp > 0 && !word_end_row_host) || (n_ref > 0 && !ref_times_host) || (n_hyp > 0 && n_ref > 0 && !same_word_host))
+    return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  if (e->probe_LH <= 0) return fail(WCA_ERR_STATE, "wca_probe_strict_tp needs a preceding wca_probe_heads");
+  if (n_heads != e->probe_LH) return fail(WCA_ERR_INVALID, "n_heads %d != the %d heads of the preceding wca_probe_heads", n_heads, e->probe_LH);
+  if (n_hyp < 0 || n_ref < 0 || n_ref > 512) return fail(WCA_ERR_INVALID, "n_hyp=%d n_ref=%d outside [0, 512]", n_hyp, n_ref);
+  for (int i = 0; i < n_hyp; ++i)
+    if (word_end_row_host[i] < 0 || word_end_row_host[i] >= e->probe_N)
+      return fail(WCA_ERR_INVALID, "word end row %d = %d outside the %d aligned token rows", i, word_end_row_host[i], e->probe_N);
+  const int LH = e->probe_LH;
+  const size_t b_wb = align_up(sizeof(int) * (size_t)std::max(n_hyp, 1), 256), b_y = align_up(sizeof(double) * (size_t)std::max(n_ref, 1), 256),
+               b_eq = align_up((size_t)std::max(n_hyp * n_ref, 1), 256), b_tp = sizeof(int) * (size_t)LH;
+  HIPCHK(e->tmp0.ensure(b_wb + b_y + b_eq + b_tp));
+  char* base = (char*)e->tmp0.p;
+  if (n_hyp) HIPCHK(hipMemcpyAsync(base, word_end_row_host, sizeof(int) * (size_t)n_hyp, hipMemcpyHostToDevice, e->stream));
+  if (n_ref) HIPCHK(hipMemcpyAsync(base + b_wb, ref_times_host, sizeof(double) * (size_t)n_ref, hipMemcpyHostToDevice, e->stream));
+  if (n_hyp && n_ref) HIPCHK(hipMemcpyAsync(base + b_wb + b_y, same_word_host, (size_t)n_hyp * n_ref, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(launch_probe_strict((const int*)e->probe_jump.p, e->probe_N, LH, (const int*)base, n_hyp, (const double*)(base + b_wb), n_ref,
+                             (const unsigned char*)(base + b_wb + b_y), tolerance, (int*)(base + b_wb + b_y + b_eq), e->stream));
+  HIPCHK(hipMemcpyAsync(tp_host, base + b_wb + b_y + b_eq, b_tp, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
   return WCA_OK;
 }

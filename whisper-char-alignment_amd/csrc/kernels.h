@@ -182,6 +182,10 @@ hipError_t launch_aggregate(const AggregateArgs& a, hipStream_t s);
 hipError_t launch_stdmean_normalize(const float* ws, const int* sel_dev, int n_sel, int n, int F, float* out, hipStream_t s);
 hipError_t launch_mean_heads(const float* x, int n_sel, int n, int F, int row_lo, int row_hi_trim, float* matrix, hipStream_t s);
 
+// per-head strict word-boundary scoring of the probe (metrics.py:45-72 over every head of probe_oracle.py:83-90): tp_out[hd]
+hipError_t launch_probe_strict(const int* jump, int jump_ld, int LH, const int* wb_end, int n_hyp, const double* y, int n_ref,
+                               const unsigned char* eq, double tol, int* tp_out, hipStream_t s);
+
 // standalone median filter along the last axis with reflect padding (whisper.timing.median_filter)
 hipError_t launch_median_filter(const float* in, float* out, long rows, int F, int width, hipStream_t s);
 

@@ -355,6 +355,32 @@ __global__ __launch_bounds__(256) void median_filter_kernel(const float* __restr
   }
 }
 
+// probe_oracle.py:83-90 + metrics.py:45-72 (eval_n1_strict) for every head at once: head hd's predicted word boundaries are
+// jump[hd][wb_end[i]] / 50 s; a prediction i counts if an UNUSED reference boundary j of the same word (eq[i][j]) lies within
+// `tol` -- first such j in order, as the reference's double loop. One thread per head; times in double like the host code
+// (frames / 50.0 compared in float64), so tp is the same integer.
+__global__ __launch_bounds__(64) void probe_strict_kernel(const int* __restrict__ jump, int jump_ld, int LH, const int* __restrict__ wb_end,
+                                                          int n_hyp, const double* __restrict__ y, int n_ref,
+                                                          const unsigned char* __restrict__ eq, double tol, int* __restrict__ tp_out) {
+  const int hd = blockIdx.x * blockDim.x + threadIdx.x;
+  if (hd >= LH) return;
+  unsigned long long used[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // n_ref <= 512
+  int tp = 0;
+  for (int i = 0; i < n_hyp; ++i) {
+    const double yh = (double)jump[(long)hd * jump_ld + wb_end[i]] / 50.0;
+    const unsigned char* e = eq + (long)i * n_ref;
+    for (int j = 0; j < n_ref; ++j) {
+      if (!e[j] || ((used[j >> 6] >> (j & 63)) & 1ull)) continue;
+      if (fabs(y[j] - yh) <= tol) {
+        used[j >> 6] |= 1ull << (j & 63);
+        ++tp;
+        break;
+      }
+    }
+  }
+  tp_out[hd] = tp;
+}
+
 }  // namespace
 
 hipError_t launch_head_stats(const HeadStatsArgs& a, hipStream_t s) {
@@ -404,6 +430,14 @@ hipError_t launch_mean_heads(const float* x, int n_sel, int n, int F, int row_lo
   const int rows = n - row_lo - row_hi_trim;
   if (n_sel <= 0 || rows <= 0 || F <= 0) return hipSuccess;
   hipLaunchKernelGGL(mean_heads_kernel, dim3((F + 255) / 256, rows), dim3(256), 0, s, x, n_sel, n, F, row_lo, row_hi_trim, matrix);
+  return hipGetLastError();
+}
+
+hipError_t launch_probe_strict(const int* jump, int jump_ld, int LH, const int* wb_end, int n_hyp, const double* y, int n_ref,
+                               const unsigned char* eq, double tol, int* tp_out, hipStream_t s) {
+  if (LH <= 0) return hipSuccess;
+  if (n_ref > 512 || n_ref < 0 || n_hyp < 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(probe_strict_kernel, dim3((LH + 63) / 64), dim3(64), 0, s, jump, jump_ld, LH, wb_end, n_hyp, y, n_ref, eq, tol, tp_out);
   return hipGetLastError();
 }
 

@@ -51,6 +51,29 @@ def probe_heads(model, w, sot_len):
     return scores, jumps
 
 
+def probe_strict_tp(model, n_heads, wb_end, ref_ends, ref_words, hyp_words, tolerance):
+    """eval_n1_strict (metrics.py:45-72) of every head of the preceding probe_heads call, on the device: tp [L*H] int32."""
+    import string
+    rw = [w.lower().strip(string.punctuation) for w in ref_words]
+    hw = [w.lower().strip(string.punctuation) for w in hyp_words]
+    same = np.array([[1 if a == b else 0 for b in rw] for a in hw], dtype=np.uint8).reshape(len(hw), len(rw))
+    wb_end = np.ascontiguousarray(wb_end, dtype=np.int32)
+    y = np.ascontiguousarray(ref_ends, dtype=np.float64)
+    tp = np.zeros(int(n_heads), dtype=np.int32)
+    _lib.check(model._lib.wca_probe_strict_tp(model._h, int(n_heads), wb_end.ctypes.data_as(C.c_void_p), len(hw), y.ctypes.data_as(C.c_void_p), len(rw),
+                                              same.ctypes.data_as(C.c_void_p), float(tolerance), tp.ctypes.data_as(C.c_void_p)))
+    return tp
+
+
+def strict_f1(tp, n_hyp, n_ref):
+    """get_seg_metrics(tp, tp, tp + fp, tp + fn)[2] for a vector of tp (the same float64 operations, metrics.py:74-86)."""
+    eps = 1e-7
+    tp = tp.astype(np.float64)
+    precision = tp / (n_hyp + eps)
+    recall = tp / (n_ref + eps)
+    return 2 * (precision * recall) / (precision + recall + eps)
+
+
 def infer_dataset(args):
     print(args)
     device = "cuda:0"
@@ -78,13 +101,14 @@ def infer_dataset(args):
             continue
         wb = np.pad(np.cumsum([len(t) for t in word_tokens[:-1]]), (1, 0))
         hyp_words = " ".join(words[:-1]).split()
-        best_f1, best_head, best_ends = -1.0, None, None
-        for hd in range(len(scores)):
-            ends_hat = (jumps[hd] / TOKENS_PER_SECOND)[wb[1:]]
-            tp, fp, fn = eval_n1_strict(ends, ends_hat, texts.split(), hyp_words, args.tolerance)
-            _, _, f1, _, _ = get_seg_metrics(tp, tp, tp + fp, tp + fn)
-            if f1 >= best_f1:
-                best_f1, best_head, best_ends = f1, hd, ends_hat
+        # every head's strict F1 (probe_oracle.py:83-90): the L*H eval_n1_strict calls run as one kernel; the oracle head is the
+        # LAST one reaching the best F1 (`if f1 >= best_f1` in the reference's loop)
+        if len(hyp_words) != len(wb) - 1:
+            raise ValueError("word split mismatch: %d words, %d boundaries" % (len(hyp_words), len(wb) - 1))
+        tp_heads = probe_strict_tp(model, len(scores), wb[1:], ends, texts.split(), hyp_words, args.tolerance)
+        f1_heads = strict_f1(tp_heads, len(hyp_words), len(ends))
+        best_head = int(np.flatnonzero(f1_heads == f1_heads.max())[-1])
+        best_ends = (jumps[best_head] / TOKENS_PER_SECOND)[wb[1:]]
         order = np.lexsort((np.arange(len(scores)), scores))  # ascending (score, head index): timing.py:36
         hits += int(best_head in set(order[-args.hit_within:].tolist()))
         n_probed += 1
