@@ -223,6 +223,28 @@ def test_gemm_residual_layernorm_rejects_unsupported_shapes(eng, lib, wca):
             wca._lib.check(lib.wca_test_gemm_ln(eng._h, _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), _vp(t), M, N, K, 1))
 
 
+@pytest.mark.parametrize("M,N,K", [(1500, 1024, 4096), (1037, 1000, 2048), (3000, 512, 2048), (200, 1280, 5120)])
+def test_gemm_residual_split_k_small_batches(eng, lib, wca, M, N, K):
+    """out_mode 2 (x += A W^T + bias) with few 128 x 128 tiles and a long K -- fc2 of a one- or two-utterance batch: K is
+    split over up to four workgroups per tile, partials added in order by a second kernel. Against fp32 torch; a second
+    launch on the same inputs gives the same bits (ordered reduction, no atomics)."""
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g, device="cuda") * 0.5).half()
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).half()
+    bias = torch.randn(N, generator=g, device="cuda")
+    x0 = torch.randn(M, N, generator=g, device="cuda") * 2.0
+    outs = []
+    for _ in range(2):
+        x = x0.clone()
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a), _vp(w), _vp(bias), _vp(x), M, N, K, 0, 2))
+        torch.cuda.synchronize()
+        outs.append(x)
+    ref = x0 + a.float() @ w.float().T + bias
+    err = float(((outs[0] - ref).abs() / (1.0 + ref.abs())).max())
+    assert err <= 2e-3, err
+    assert torch.equal(outs[0], outs[1])
+
+
 # ------------------------------------------------------------------------------- few-row GEMM (decode steps)
 def _rows_gemm(eng, lib, wca, a, x, gamma, beta, w, bias, M, N, K, gelu, out_mode, splitk=0, groups=0, c0=None, kv=None, T_max=0, t=0):
     if out_mode == 0:

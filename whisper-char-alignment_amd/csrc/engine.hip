@@ -164,6 +164,8 @@ struct wca_engine {
   float* sk_part[2] = {nullptr, nullptr};  // split-K workspaces of the few-row GEMM (one per decode stream) and their
   unsigned* sk_cnt[2] = {nullptr, nullptr};  // arrival counters (zero at creation, self-cleaning)
   size_t sk_floats = 0, sk_tiles = 0;
+  float* sk_big[2] = {nullptr, nullptr};   // split-K partials of the 128 x 128 tile GEMM (small batches: fc2), [0] encoder stream, [1] decoder
+  size_t sk_big_bytes = 0;
   int n_cu = 0;
   int* err_dev = nullptr;    // device flag raised by kernels: bit 0 token id outside the vocabulary, bit 1 LayerNorm hand-off timeout
   int* err_host = nullptr;   // pinned: read back by the synchronous entry points
@@ -318,13 +320,18 @@ size_t layout_arena(wca_engine* e, char* base) {
       e->sk_part[i] = carve<float>(cur, e->sk_floats);
       e->sk_cnt[i] = carve<unsigned>(cur, e->sk_tiles + 16, 256);
     }
+    // 128 x 128 tile GEMM with at most n_cu / 2 = 128 tiles, 4 K slices of f32 partials
+    e->sk_big_bytes = (size_t)4 * 128 * 128 * 128 * sizeof(float);
+    for (int i = 0; i < 2; ++i) e->sk_big[i] = carve<float>(cur, e->sk_big_bytes / sizeof(float));
   }
   return (size_t)(cur - base) + 4096;
 }
 
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
-                int N, int K, int gelu, int out_mode, int site = 0) {
+                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0) {
   GemmArgs g{};
+  g.sk_part = sk_ws;
+  g.sk_bytes = sk_bytes;
   g.A = A;
   g.lda = lda;
   g.W = W;
@@ -388,7 +395,7 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
     A = xn_scratch;
     lda = K;
   }
-  HIPCHK(gemm(s, A, lda, W, ldw, bias, C, ldc, M, N, K, gelu, out_mode, site));
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, C, ldc, M, N, K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes));
   if (kv_k) HIPCHK(launch_kv_append(reinterpret_cast<const half_t*>(C), kv_k, kv_v, M, T_max, kv_t, N / 3, s));
   return WCA_OK;
 }
@@ -423,7 +430,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     HIPCHK(launch_gemm(g, s));
     return WCA_OK;
   }
-  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site));
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes));
   HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s));
   return WCA_OK;
 }
@@ -2071,6 +2078,8 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   g.out_mode = out_mode & 0xff;
   g.force_tile = (out_mode >> 8) & 0xfff;  // 0 auto / 128 / 256 / 257 (persistent) / 258 (one tile per workgroup)
   g.supertile = out_mode >> 20;             // 0 = launch_gemm's choice (tools: tile-order experiments)
+  g.sk_part = e->sk_big[0];                  // few tiles, K >= 2048, out_mode 2: split-K with the engine's workspace, as the encoder does
+  g.sk_bytes = e->sk_big_bytes;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }

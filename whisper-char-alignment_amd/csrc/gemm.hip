@@ -144,10 +144,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
     } else {
       aoff = (long)gm * a.lda;
     }
-    asrc[i] = a.A + aoff + c * 8;
+    // split-K (gridDim.y > 1): this workgroup multiplies K slice blockIdx.y and stores a raw partial tile (below)
+    const int kbeg = (int)blockIdx.y * (a.K / (int)gridDim.y);
+    asrc[i] = a.A + aoff + c * 8 + kbeg;
     int gn = n0 + r;
     gn = gn < a.N ? gn : a.N - 1;
-    wsrc[i] = a.W + (long)gn * a.ldw + c * 8;
+    wsrc[i] = a.W + (long)gn * a.ldw + c * 8 + kbeg;
   }
 
   auto stage = [&](int buf, int k0) {
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
     wrow[t] = wn * 64 + (fr >> 2) * 16 + t * 4 + (fr & 3);
   }
 
-  const int nk = a.K / BK;
+  const int nk = a.K / BK / (int)gridDim.y;
   stage(0, 0);
   wait_vm0();
   __syncthreads();
@@ -206,7 +208,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmArgs a) {
     cur ^= 1;
   }
 
+  if (OUT_MODE == 2 && gridDim.y > 1) {
+    // split-K: the raw partial tile of this K slice -> workspace [slice][M][N] f32; splitk_reduce_kernel adds the slices in
+    // order, the bias and the residual (deterministic; launch_gemm runs it right behind this kernel)
+    GemmArgs p = a;
+    p.C = a.sk_part + (long)blockIdx.y * a.M * a.N;
+    p.ldc = a.N;
+    p.c_rows_per_batch = 0;
+    p.bias = nullptr;
+    p.pos = nullptr;
+    epilogue<1, false, 4>(p, acc, m0 + wm * 64, n0 + wn * 64 + fg * 16, fr);
+    return;
+  }
   epilogue<OUT_MODE, GELU, 4>(a, acc, m0 + wm * 64, n0 + wn * 64 + fg * 16, fr);
+}
+
+// x[m][n] += bias[n] + sum_s part[s][m][n] (slices in order): second half of the split-K residual GEMM
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, const float* __restrict__ bias,
+                                                            float* __restrict__ x, int ldc) {
+  const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;  // one float4 of the [M][N] output
+  const int n4 = N >> 2;
+  if (i4 >= (long)M * n4) return;
+  const int m = (int)(i4 / n4), n = (int)(i4 - (long)m * n4) * 4;
+  f32x4 v = *reinterpret_cast<const f32x4*>(part + (long)m * N + n);
+  for (int s = 1; s < S; ++s) v += *reinterpret_cast<const f32x4*>(part + ((long)s * M + m) * N + n);
+  if (bias != nullptr) v += *reinterpret_cast<const f32x4*>(bias + n);
+  f32x4* xp = reinterpret_cast<f32x4*>(x + (long)m * ldc + n);
+  *xp = *xp + v;
 }
 
 
@@ -808,6 +836,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   const bool big = want_big;
   dim3 grid, block;
   size_t shmem;
+  int splitk = 1;
   if (big) {
     grid = dim3((unsigned)tiles256);
     block = dim3(512);
@@ -825,6 +854,18 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     grid = dim3(ntn * ntm);
     block = dim3(256);
     shmem = 2 * 2 * TILE_ELEMS * sizeof(half_t);  // 64 KiB
+    // few tiles and a long K (fc2 of a one- or two-utterance batch: 96 tiles x 64 K tiles): split K over up to 4 workgroups
+    // per tile; partial tiles go to the caller's workspace and a second kernel adds them in order (deterministic)
+    splitk = 1;
+    if (a.out_mode == 2 && !a.gelu && a.sk_part != nullptr && a.pos == nullptr && a.c_rows_per_batch == 0 && (a.N % 4) == 0 && (a.ldc % 4) == 0 &&
+        ntn * ntm <= n_cu / 2 && a.K >= 2048) {
+      for (int sk = 4; sk >= 2; --sk)
+        if (a.K % (sk * BK) == 0 && (size_t)sk * a.M * a.N * sizeof(float) <= a.sk_bytes) {
+          splitk = sk;
+          break;
+        }
+    }
+    grid.y = (unsigned)splitk;
   }
   // the dynamic-LDS limit is a per-device property of each kernel symbol: remembered per (symbol, device) so that several
   // engines (one per GPU) in one process and concurrent host threads are served correctly
@@ -893,6 +934,15 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
 #undef WCA_LAUNCH_K4
+  {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  if (splitk > 1) {
+    const long n4 = (long)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, a.sk_part, splitk, a.M, a.N, a.bias,
+                       reinterpret_cast<float*>(a.C), a.ldc);
+  }
   return hipGetLastError();
 }
 

@@ -52,6 +52,8 @@ struct GemmArgs {
   half_t* kv_v;            // columns [2 kv_d, 3 kv_d) to kv_v + ... (the step's KV-cache append); columns [0, kv_d) to C as usual
   long kv_bs;              // elements between batch rows of a cache plane (T_max * d)
   int kv_t, kv_d;
+  size_t sk_bytes;         // launch_gemm (128 x 128 tile kernel, out_mode 2, few tiles and K >= 2048): bytes behind sk_part; it then
+                           // splits K over up to 4 workgroups per tile ([slice][M][N] f32 partials + an ordered reduce kernel)
   float* sk_part;          // split-K workspace (gemm_rows_workspace_bytes) and
   unsigned* sk_cnt;        // one arrival counter per (64-row block, 16-column group), zero before the first launch (self-cleaning)
   int splitk;              // workgroups sharing K (0 = chosen by launch_gemm_rows: smallest with K / splitk <= 1024)
