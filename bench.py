@@ -284,9 +284,12 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
-    if world > 1:
+    # WCA_FORCE_DIST=1 with one rank: the RCCL collation path (process group, GPU all-gathers, barriers) exactly as at N > 1, so that
+    # it can be exercised on a 1-GPU box (two ranks cannot share one device under RCCL)
+    if world > 1 or os.environ.get("WCA_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("WCA_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a 1-GPU box
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

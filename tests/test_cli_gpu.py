@@ -311,3 +311,31 @@ print("snippet ok")
            pcm=os.path.join(GOLD, "sample_pcm_int16.npy"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "snippet ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_bench_line_contract_and_rccl_collation_path():
+    """bench.py end to end on a tiny model: ONE JSON line with the contract's keys + roofline + cpu_baseline, the oracle parity
+    leg at the timed configuration, and (WCA_FORCE_DIST=1) the RCCL process group / GPU all-gather / barrier path that the
+    N > 1 runs take, with one rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WCA_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "tiny", "--batch", "4", "--steps", "4", "--warmup", "1",
+                        "--distinct-batches", "2", "--seconds", "4", "--chars", "24", "--cpu-utts", "2"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["dtype"] == "f16" and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
+    par = cb["parity"]
+    assert par["batch_invariant"] and par["offending_boundaries_in_well_conditioned_utterances"] == 0, par
