@@ -76,9 +76,12 @@ def test_config3_large_v2_char_max_sizes(wca, large_v2, aggr, topk):
     jump, sel = model.align_batch(pcm_d, [480000] * B, tok_d, [448] * B, [1500] * B, opts)
     dt = time.time() - t1
     _log("configs[3] char   aggr=%-4s B=%d n=448 F=1500 fused align_batch: %.1f ms per batch (%.2f utt/s)" % (aggr, B, dt * 1e3, B / dt))
+    # the step-by-step API on the SAME micro-batch (same GEMM kernels and summation orders as the fused path: a batch of one
+    # takes other kernels -- split-K fc2, few-row decoder GEMMs -- whose last-bit differences can move a near-tied DTW step)
+    mels = torch.stack([audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm[b])), 80, model=model) for b in range(B)]).cuda()
+    w_all, _ = model.get_attentions(mels, tok_d, [1500] * B, 7, 1.0, want_logits=False)
     for b in range(B):
-        mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm[b])), 80, model=model)
-        w, _ = tm.get_attentions(mel, tok_d[b], model, tok, 1500, medfilt_width=7)
+        w = w_all[b]
         assert tuple(w.shape) == (32, 20, 448, 1500)
         t2 = time.time()
         words, st, en, matrix, scores = tm.force_align(w, tts[b], tok, "char", aggr, topk=topk)
