@@ -369,3 +369,27 @@ def test_dropin_module_names_resolve():
         "print('ok')\n" % os.path.join(root, "whisper-char-alignment_amd", "dropin"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]
+
+
+def test_bench_conditioning_probe_separates_sharp_from_flat_matrices():
+    """bench.py's parity leg labels an utterance ill-conditioned when the ORACLE's own DTW path moves under relative noise on
+    its aggregated matrix: a sharp diagonal map must be stable, a flat one (every path costs the same) must not."""
+    import importlib.util
+    import os
+    import torch
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from oracle import timing_ref, tokenizer_ref
+    tok = tokenizer_ref.CharTokenizer()
+    tt = tokenizer_ref.encode_char("one two three four", tok)
+    _w, wt = tokenizer_ref.split_tokens_on_spaces(list(tt) + [tok.eot], tok, "char")
+    n, F = len(tt) + 1, 240
+    rows = torch.arange(n).float()[:, None]
+    cols = torch.arange(F).float()[None, :]
+    sharp = torch.exp(-0.5 * ((cols - (rows + 0.5) * F / n) / 3.0) ** 2) + 1e-3     # a clear diagonal ridge
+    flat = torch.full((n, F), 0.5)
+    for m, expect in ((sharp, False), (flat, True)):
+        ti, tj = timing_ref.dtw(-m)
+        st, en = timing_ref.jumps_to_times(ti, tj, wt)
+        assert bench.oracle_is_ill_conditioned(m, tt, st, en) is expect
