@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=32, help="utterances timed by the CPU baseline (after 1 warm-up)")
+    ap.add_argument("--aligned-utts", type=int, default=8, help="utterances of the second parity leg (alignment-like planted checkpoint: "
+                    "synthetic.aligned_state_dict), aligned by the CPU oracle and by the GPU path in a full batch; 0 = skip")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorms inside the residual GEMMs' epilogues instead of separate launches (A/B)")
     ap.add_argument("--dec-unfused", action="store_true", help="decoder GEMMs on <= 256 rows as separate LayerNorm / GEMM launches (A/B of the few-row kernel; matters at small batch)")
@@ -253,6 +255,57 @@ def parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_tim
             "batch_invariant": bool(invariant), "weights": "peaky (cross_qk_std=0.08)", "tolerance": "one 20 ms encoder frame (north_star)"}
 
 
+def parity_alignment_like(args, wca, dims, syn, audio_mod, tok_mod, retok, timing, device):
+    """Second parity leg, not timed: the same pipeline on a checkpoint whose cross-attention looks like a trained Whisper's
+    alignment heads (synthetic.aligned_state_dict: sharp monotonic ridges in 12 planted heads, separated head scores, words
+    spread over the audio). With random weights the maps carry no alignment and a few utterances are decided by rounding
+    (first leg); here the DTW is well conditioned and the selection unambiguous, so the GPU path must reproduce the fp32
+    oracle exactly: same heads in the same order, identical word times."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    sd = syn.aligned_state_dict(dims, seed=0)
+    model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch).load_state_dict(sd)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    tok = tok_mod.get_tokenizer(True, language="English")
+    rtok = tokenizer_ref.CharTokenizer()
+    filt = audio_mod.mel_filters(dims.n_mels)
+    n_samples = int(args.seconds * 16000)
+    ids = [20_000 + u for u in range(args.aligned_utts)]
+    fill = (ids * ((args.batch + len(ids) - 1) // len(ids)))[:args.batch]
+    pcm = np.stack([syn.synth_audio(u, n_samples) for u in fill])
+    texts = [syn.synth_text(u, args.chars) for u in fill]
+    tts = [retok.encode(t, tok, "char") for t in texts]
+    rows = [[*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot] for tt in tts]
+    n_max = max(len(r) for r in rows)
+    toks = np.full((len(rows), n_max), tok.eot, dtype=np.int64)
+    for j, r in enumerate(rows):
+        toks[j, :len(r)] = r
+    opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width, qk_scale=1.0)
+    jump, sel = model.align_batch(torch.from_numpy(pcm).to(device), [n_samples] * len(fill), torch.from_numpy(toks).to(device),
+                                  [len(r) for r in rows], [n_samples // 320] * len(fill), opts)
+    H = dims.n_text_head
+    total = within = identical = heads_same = 0
+    span = []
+    for j in range(len(ids)):
+        mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm[j])), filt)
+        tt = tokenizer_ref.encode_char(texts[j], rtok)
+        tokens = torch.tensor([*rtok.sot_sequence, rtok.no_timestamps, *tt, rtok.eot])
+        w, _ = timing_ref.get_attentions(mel, tokens, ref, n_samples // 320, args.medfilt_width, 1.0)
+        _words, rst, ren, _m, rscores = timing_ref.force_align(w, tt, rtok, "char", "topk", args.topk)
+        _w, st, en = timing.words_from_jump_frames(jump[j], tts[j], tok, "char")
+        for a, b in ((np.asarray(st), np.asarray(rst)), (np.asarray(en), np.asarray(ren))):
+            total += len(a)
+            within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
+            identical += int(np.sum(a == b))
+        heads_same += int([int(h) for h in sel[j][:args.topk]] == [l * H + h for _s, (l, h), _n in rscores])
+        span.append(float(ren[-1] - rst[min(1, len(rst) - 1)]))
+        print("alignment-like parity utterance %d/%d" % (j + 1, len(ids)), file=sys.stderr, flush=True)
+    del model
+    torch.cuda.empty_cache()
+    return {"checkpoint": "synthetic.aligned_state_dict(seed=0): 12 planted alignment heads, ridge at 7 frames per token", "utterances": len(ids),
+            "word_boundaries": total, "within_one_frame": within, "identical": identical, "utterances_with_identical_head_selection": heads_same,
+            "mean_span_of_aligned_words_s": float(np.mean(span)) if span else None}
+
+
 def measured_traffic(args, dims, site):
     """HBM-side bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes recorded under
     profiles/ (tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
@@ -412,6 +465,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times)
             # same utterances through the GPU path at the timed configuration, checked against the oracle's word times
             out["cpu_baseline"]["parity"] = parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device)
+            if args.aligned_utts > 0:
+                out["cpu_baseline"]["parity_alignment_like"] = parity_alignment_like(args, wca, dims, syn, audio_mod, tok_mod, retok, timing, device)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

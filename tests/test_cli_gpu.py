@@ -324,7 +324,7 @@ def test_bench_line_contract_and_rccl_collation_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, WCA_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "tiny", "--batch", "4", "--steps", "4", "--warmup", "1",
-                        "--distinct-batches", "2", "--seconds", "4", "--chars", "24", "--cpu-utts", "2"], capture_output=True, text=True,
+                        "--distinct-batches", "2", "--seconds", "4", "--chars", "24", "--cpu-utts", "2", "--aligned-utts", "2"], capture_output=True, text=True,
                        timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
@@ -339,3 +339,5 @@ def test_bench_line_contract_and_rccl_collation_path():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0
     par = cb["parity"]
     assert par["batch_invariant"] and par["offending_boundaries_in_well_conditioned_utterances"] == 0, par
+    pal = cb["parity_alignment_like"]
+    assert pal["utterances"] == 2 and pal["word_boundaries"] > 0 and pal["within_one_frame"] == pal["word_boundaries"], pal

@@ -64,6 +64,42 @@ def random_state_dict(dims, seed=0, std=0.02, cross_qk_std=None, dtype=torch.flo
     return sd
 
 
+def aligned_state_dict(dims, seed=0, frames_per_token=7.0, text_row0=3, branch_scale=0.05, dtype=torch.float16):
+    """random_state_dict with ALIGNMENT-LIKE cross-attention planted into head 0 of the upper half of the decoder layers (what a
+    trained Whisper's alignment heads look like to the alignment pipeline: a sharp monotonic ridge, well separated head scores),
+    for parity tests on maps that resemble the real use. Construction: the residual branches (attention out-projections, mlp.2)
+    are damped by `branch_scale` so that positions survive the stack; decoder position p carries the ENCODER's sinusoid code
+    of time t = frames_per_token * (p - text_row0); the planted heads' cross-attention query / key projections select 32
+    (sin, cos) channel pairs of that code, so q.k = g^2 * sum_c cos(w_c (t_p - f)) peaks at frame f = t_p. Gains differ per
+    layer so that the planted heads' selection scores are not tied. Data generation only."""
+    sd = random_state_dict(dims, seed=seed, dtype=dtype)
+    d, dt = dims.n_audio_state, dims.n_text_state
+    assert d == dt and d >= 128
+    for k in list(sd):
+        if k.endswith(".out.weight") or k.endswith(".out.bias") or k.endswith(".mlp.2.weight") or k.endswith(".mlp.2.bias"):
+            sd[k] = (sd[k].float() * branch_scale).to(dtype)
+    half = d // 2
+    inc = np.log(10000) / (half - 1)
+    inv = torch.exp(-inc * torch.arange(half))
+    t = frames_per_token * (torch.arange(dims.n_text_ctx).float() - text_row0)
+    sd["decoder.positional_embedding"] = torch.cat([torch.sin(t[:, None] * inv[None, :]), torch.cos(t[:, None] * inv[None, :])], dim=1).to(dtype)
+    chans = [min(half - 1, (half // 64) * 2 * i) for i in range(32)]   # wavelengths from ~6 to ~600 frames at d = 1024
+    L = dims.n_text_layer
+    for li in range(L // 2, L):
+        gain = 1.2 + 0.6 * (li - L // 2) / max(1, L - L // 2 - 1)
+        for name in ("query", "key"):
+            w = sd[f"decoder.blocks.{li}.cross_attn.{name}.weight"].float()
+            w[:64] = 0.0
+            for r, c in enumerate(chans):
+                w[r, c] = gain
+                w[32 + r, half + c] = gain
+            sd[f"decoder.blocks.{li}.cross_attn.{name}.weight"] = w.to(dtype)
+        b = sd[f"decoder.blocks.{li}.cross_attn.query.bias"].float()
+        b[:64] = 0.0
+        sd[f"decoder.blocks.{li}.cross_attn.query.bias"] = b.to(dtype)
+    return sd
+
+
 def synth_audio(utt_id, n_samples=160000):
     """0.1*N(0,1) gated by a 4 Hz square envelope, clipped to [-1,1] (exercises the max-8 dB floor)."""
     rng = np.random.default_rng(1234 + int(utt_id))
