@@ -39,12 +39,12 @@ MFMA_F16_DENSE_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16/f
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SITE_SYMBOL = {
     "qkv": "gemm256p_f16_kernel<0, false, 1, false> (encoder QKV projection, N=3d K=d)",
-    "attention": "attn_kernel<false, false, false> (encoder self-attention 1500x1500, head_dim 64)",
-    "out_proj": "gemm256p_f16_kernel<2, false, 1, false> + layernorm_f16 (encoder attention out-projection + residual, then mlp_ln; N=d K=d)",
+    "attention": "attn32_kernel<false> (encoder self-attention 1500x1500, head_dim 64)",
+    "out_proj": "gemm256p_f16_kernel<2, false, 1, false> (encoder attention out-projection + f32 residual read-modify-write; N=d K=d; with --fuse-ln the <3, ...> kernel incl. mlp_ln)",
     "fc1": "gemm256p_f16_kernel<0, true, 1, false> (encoder MLP fc1 + GELU, N=4d K=d)",
-    "fc2": "gemm256p_f16_kernel<2, false, 4, false> + layernorm_f16 (encoder MLP fc2 + residual, then the next attn_ln / ln_post; N=d K=4d)",
-    "ln1": "layernorm_f16 (attn_ln of layer 0)",
-    "ln2": "unused",
+    "fc2": "gemm256p_f16_kernel<2, false, 4, false> (encoder MLP fc2 + f32 residual read-modify-write; N=d K=4d; with --fuse-ln the <3, ...> kernel incl. the next attn_ln)",
+    "ln1": "layernorm_f16_v4_kernel (attn_ln launches + ln_post)",
+    "ln2": "layernorm_f16_v4_kernel (mlp_ln launches)",
 }
 
 
@@ -400,10 +400,28 @@ def main():
     results = {}
     t0 = time.perf_counter()
     # software pipeline of depth 2: the host tail of step i-1 runs while the GPU executes step i
+    SITES = ("qkv", "attention", "out_proj", "fc1", "fc2", "ln1", "ln2")
+    site_acc = {s: [0, 0.0, 0.0, 0.0] for s in SITES}   # launches, summed ms, flops / launch, bytes / launch
+    sampled_steps = 0
+
+    def sample_sites():
+        # HIP-event pairs around every launch of every encoder kernel of the batch enqueued last (recorded on the engine's
+        # stream by each enqueue); reading them waits for that batch, so only every 8th step is sampled (a sampled step delays
+        # the next enqueue by the read: ~0.2 % of the timed region)
+        nonlocal sampled_steps
+        for s_ in SITES:
+            n, ms, fl, by = model.kernel_ms(s_)
+            site_acc[s_][0] += n
+            site_acc[s_][1] += ms
+            site_acc[s_][2], site_acc[s_][3] = fl, by
+        sampled_steps += 1
+
     for i in range(args.steps):
         enqueue(i)
         if i > 0:
             finish(i - 1, results)
+        if i % 8 == 7 and i + 1 < args.steps:
+            sample_sites()
     finish(args.steps - 1, results)
     # collate exactly like infer_ali.py does: packed (index, n, starts, ends) records through one size gather + one
     # all-gather, and the 3-counter all-reduce (the only collectives on the path; no-ops for one rank)
@@ -416,7 +434,8 @@ def main():
     elapsed = time.perf_counter() - t0
     # HIP-event pairs around every launch of every encoder kernel were recorded on the engine stream during the
     # last timed step (they are re-recorded by each enqueue)
-    sites = {s: model.kernel_ms(s) for s in ("qkv", "attention", "out_proj", "fc1", "fc2", "ln1", "ln2")}
+    sample_sites()   # the last step (complete: its results were fetched)
+    sites = {s_: tuple(site_acc[s_]) for s_ in SITES}
     stage_ms = model.last_stage_ms() if args.stages else None
     model.set_profiling(False)
     assert len(merged) == world * args.steps * args.batch and counters[0] == len(merged)
@@ -451,7 +470,7 @@ def main():
                        "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region",
                        "pipeline_tflops": total_utts * 1.356 / elapsed, "commit": git_head()},
             "roofline": {"bound": "mfma", "kernel": "%s, M=%d d=%d" % (SITE_SYMBOL[dom], args.batch * 1500, d),
-                         "selected_as": "largest total time of the encoder kernel sites in the last timed step",
+                         "selected_as": "largest total time of the encoder kernel sites over the sampled steps of the timed region (every 8th step + the last: %d steps)" % sampled_steps,
                          "achieved": kernels[dom]["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": sites[dom][3], "algorithmic_flops": sites[dom][2],
@@ -461,7 +480,7 @@ def main():
         if stage_ms is not None:
             names = ["logmel", "encoder", "cross_kv", "decoder", "head_stats", "topk_aggregate", "dtw", "total"]
             print("stage ms/step (last step): " + ", ".join("%s=%.3f" % (n, v) for n, v in zip(names, stage_ms)), file=sys.stderr)
-            print("encoder kernel sites (last step): " + ", ".join("%s=%.3f ms x%d (%.0f %s)" % (
+            print("encoder kernel sites (%d sampled steps of the timed region): " % sampled_steps + ", ".join("%s=%.3f ms x%d (%.0f %s)" % (
                 s, k["avg_launch_ms"], k["launches"], k["achieved"], k["unit"]) for s, k in kernels.items()), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             oracle_times = []

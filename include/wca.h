@@ -297,11 +297,11 @@ int wca_last_stage_ms(wca_engine* e, float* ms8);
 enum {
   WCA_SITE_QKV = 0,   /* encoder self-attention q/k/v projection   gemm256p<0,false,1>  N = 3d, K = d   */
   WCA_SITE_ATTN = 1,  /* encoder self-attention (flash)            attn_kernel<false,false>             */
-  WCA_SITE_OUT = 2,   /* attention out-projection + residual (+ mlp_ln: gemm256p<3,..> fused, else + layernorm launch)  */
+  WCA_SITE_OUT = 2,   /* attention out-projection + residual: gemm256p<2,false,1> alone (or the fused gemm256p<3,..> + mlp_ln)  */
   WCA_SITE_FC1 = 3,   /* MLP fc1 + GELU                            gemm256p<0,true,1>   N = 4d, K = d   */
-  WCA_SITE_FC2 = 4,   /* MLP fc2 + residual (+ the next attn_ln / ln_post, same two forms)                             */
-  WCA_SITE_LN1 = 5,   /* attn_ln of layer 0                                                                            */
-  WCA_SITE_LN2 = 6,   /* unused (the other LayerNorms are timed with the GEMM that feeds them: sites 2 and 4)          */
+  WCA_SITE_FC2 = 4,   /* MLP fc2 + residual: gemm256p<2,false,4> alone (or fused with the next attn_ln / ln_post)                */
+  WCA_SITE_LN1 = 5,   /* attn_ln launches (slot li = the layer they feed; slot n_layer = ln_post)                                */
+  WCA_SITE_LN2 = 6,   /* mlp_ln launches                                                                                         */
   WCA_N_SITES = 7
 };
 int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms, double* flops_per_launch,

@@ -403,8 +403,18 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
 // x (f32 residual stream, [M][N]) += A W^T + bias, then xn (f16) = LayerNorm(x) with (gamma, beta): ONE kernel where the
 // persistent GEMM can exchange the row statistics between the workgroups of a 256-row panel (gemm_epilogue.h, out_mode 3);
 // otherwise (few tiles: the decoder, small batches) the read-modify-write GEMM followed by the LayerNorm kernel.
+// ev_gemm / ev_ln (profiling): event slots {site, layer} for the GEMM and for the LayerNorm launch; the fused kernel is timed
+// as the GEMM's site alone.
 int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, float* x, int M, int N,
-                     int K, const float* gamma, const float* beta, half_t* xn, int site, bool allow_fused = true) {
+                     int K, const float* gamma, const float* beta, half_t* xn, int site, bool allow_fused = true, int ev_gemm_site = -1,
+                     int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0) {
+  auto ev = [&](int st, int li, int which) {
+    if (e->profiling && st >= 0 && li >= 0 && li < 32) {
+      (void)hipEventRecord(e->kev[st][li][which], s);
+      e->kev_set[st][li] = true;
+    }
+  };
+  ev(ev_gemm_site, ev_gemm_li, 0);
   if (allow_fused && gemm_ln_supported(M, N, K, e->n_cu)) {
     GemmArgs g{};
     g.A = A;
@@ -428,10 +438,14 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     g.ln_cnt = e->ln_cnt;
     g.ln_err = e->err_dev;
     HIPCHK(launch_gemm(g, s));
+    ev(ev_gemm_site, ev_gemm_li, 1);
     return WCA_OK;
   }
   HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes));
+  ev(ev_gemm_site, ev_gemm_li, 1);
+  ev(ev_ln_site, ev_ln_li, 0);
   HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s));
+  ev(ev_ln_site, ev_ln_li, 1);
   return WCA_OK;
 }
 
@@ -610,18 +624,18 @@ int run_encoder(wca_engine* e, int B) {
     mark(WCA_SITE_ATTN, li, 0);
     HIPCHK(launch_attention(a, s));
     mark(WCA_SITE_ATTN, li, 1);
-    mark(WCA_SITE_OUT, li, 0);
-    if (int rc = gemm_residual_ln(e, s, e->att, d, l.out_w, d, l.out_b, e->x, M, d, d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln)) return rc;
-    mark(WCA_SITE_OUT, li, 1);
+    // sites OUT / FC2 = the GEMM alone (or the fused GEMM + LayerNorm kernel); the LayerNorm launches: mlp_ln = LN2[li], the next
+    // layer's attn_ln / ln_post = LN1[li + 1]
+    if (int rc = gemm_residual_ln(e, s, e->att, d, l.out_w, d, l.out_b, e->x, M, d, d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln, WCA_SITE_OUT, li,
+                                  WCA_SITE_LN2, li))
+      return rc;
     mark(WCA_SITE_FC1, li, 0);
     HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0, 1));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
-    mark(WCA_SITE_FC2, li, 0);
     if (int rc = gemm_residual_ln(e, s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, M, d, 4 * d, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
-                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, 4, fuse_ln))
+                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, 4, fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1))
       return rc;
-    mark(WCA_SITE_FC2, li, 1);
   }
   return WCA_OK;
 }
@@ -1167,9 +1181,9 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   switch (site) {
     case WCA_SITE_QKV: fl = 2 * M * 3 * d * d; by = 2 * (M * d + 3 * d * d + M * 3 * d); break;
     case WCA_SITE_ATTN: fl = 4.0 * e->last_batch * H * (double)N_CTX * N_CTX * 64; by = 2 * (M * 3 * d + M * d); break;
-    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d + (e->fuse_ln ? 2 : 6) * M * d; break;  // f32 residual read + write, + the LayerNorm (fused: f16 out; launch: f32 in, f16 out)
+    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d + (e->fuse_ln ? 2 : 0) * M * d; break;  // f32 residual read + write (+ the fused LayerNorm's f16 output)
     case WCA_SITE_FC1: fl = 2 * M * 4 * d * d; by = 2 * (M * d + 4 * d * d + M * 4 * d); break;
-    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d + (e->fuse_ln ? 2 : 6) * M * d; break;
+    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d + (e->fuse_ln ? 2 : 0) * M * d; break;
     case WCA_SITE_LN1:
     case WCA_SITE_LN2: fl = 8 * M * d; by = 6 * M * d; break;                                    // read f32, write f16
   }
