@@ -189,6 +189,29 @@ def test_decode_modes_agree(pkg):
     np.testing.assert_allclose(ns0, ns1, rtol=1e-4, atol=1e-7)
 
 
+def test_decode_stops_when_every_row_has_ended(pkg, small):
+    """The loop's early exit (every row produced EOT; checked every 4 steps) in both stream modes: with every token but EOT
+    suppressed the first sampled token of every row is EOT, the rows report zero sampled tokens and the remaining positions
+    are EOT-filled."""
+    m, sd, dims = small
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims, without_timestamps=True)
+    only_eot = np.ones(dims.n_vocab, np.uint8)
+    only_eot[tok.eot] = 0
+    B = 4
+    pcm = torch.from_numpy(np.stack([syn.synth_audio(70 + b, n_samples=32000) for b in range(B)])).cuda()
+    ns = np.full(B, 32000, np.int32)
+    initial = list(tok.sot_sequence) + [tok.no_timestamps]
+    for streams in (1, 2):
+        m.set_decode_mode(True, streams)
+        toks, n_tok, lp = m.greedy_decode(None, pcm, ns, initial, only_eot, None, sample_len=40, eot=tok.eot,
+                                          timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=False, max_initial_timestamp_index=-1)
+        assert (n_tok == len(initial)).all()
+        assert (toks[:, len(initial):] == tok.eot).all()
+        assert np.allclose(lp, 0.0, atol=1e-5)      # log-softmax over a single live token
+    m.set_decode_mode(True, 1)
+
+
 def test_decode_api_and_encoder_reuse(pkg, small, fake_vocab):
     """whisper.decode mirror + the alignment that follows re-uses the encoder state (pcm=None) and gives the same
     jump frames as a from-scratch align_batch on the same tokens."""
