@@ -296,7 +296,7 @@ int wca_last_stage_ms(wca_engine* e, float* ms8);
  * written once, f32 residual read + written for the two read-modify-write GEMMs). */
 enum {
   WCA_SITE_QKV = 0,   /* encoder self-attention q/k/v projection   gemm256p<0,false,1>  N = 3d, K = d   */
-  WCA_SITE_ATTN = 1,  /* encoder self-attention (flash)            attn_kernel<false,false>             */
+  WCA_SITE_ATTN = 1,  /* encoder self-attention (flash)            attn32_kernel<false>                 */
   WCA_SITE_OUT = 2,   /* attention out-projection + residual: gemm256p<2,false,1> alone (or the fused gemm256p<3,..> + mlp_ln)  */
   WCA_SITE_FC1 = 3,   /* MLP fc1 + GELU                            gemm256p<0,true,1>   N = 4d, K = d   */
   WCA_SITE_FC2 = 4,   /* MLP fc2 + residual: gemm256p<2,false,4> alone (or fused with the next attn_ln / ln_post)                */
