@@ -68,7 +68,89 @@ def parse():
     ap.add_argument("--fuse-ln", action="store_true", help="LayerNorms inside the residual GEMMs' epilogues instead of separate launches (A/B)")
     ap.add_argument("--dec-unfused", action="store_true", help="decoder GEMMs on <= 256 rows as separate LayerNorm / GEMM launches (A/B of the few-row kernel; matters at small batch)")
     ap.add_argument("--no-overlap", action="store_true", help="phase 2 on the same stream as phase 1 (clean per-kernel rocprofv3 averages)")
+    ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collation rehearsal without a GPU: every rank fabricates its "
+                    "shard's results instead of aligning (CPU tests of the --gpus N self-launch with WCA_DIST_BACKEND=gloo)")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` run plainly (no launcher, WORLD_SIZE unset): start N ranks -- one process per GPU, through
+    torch.distributed.run exactly as the driver's own command line would -- BEFORE this process touches a GPU, relay rank 0's
+    JSON line and exit with the launcher's code. Fails loudly when fewer than N devices are visible."""
+    import socket
+    backend = os.environ.get("WCA_DIST_BACKEND", "nccl")
+    if backend == "nccl" and not args.dry_run:
+        have = torch.cuda.device_count()  # counts devices without initialising the runtime
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (one rank per GPU over RCCL)" % (args.gpus, have))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this pool
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for raw in proc.stdout:
+        txt = raw.strip()
+        is_line = False
+        if txt.startswith("{"):
+            try:
+                is_line = "metric" in json.loads(txt)
+            except ValueError:
+                pass
+        if is_line:
+            line = txt
+        else:
+            sys.stderr.write(raw)  # anything else the ranks print stays out of the one-line contract
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    if line is None:
+        raise SystemExit("bench.py --gpus %d: the %d ranks finished without a result line" % (args.gpus, args.gpus))
+    rec = json.loads(line)
+    if rec.get("n_gpus") != args.gpus or rec.get("config", {}).get("dist_ranks") != args.gpus:
+        raise SystemExit("bench.py --gpus %d: the process group reported %s ranks" % (args.gpus, rec.get("config", {}).get("dist_ranks")))
+    print(line, flush=True)
+
+
+def dry_run(args, dist, rank, world):
+    """The N-rank harness without the engine: each rank fabricates the word times of its utterance shard, then runs the product's
+    collation and the contract's barrier / max-over-ranks timing. Exercises launcher, rendezvous and collectives on CPU."""
+    shard = importlib.import_module("whisper-char-alignment_amd.shard")
+    results = {}
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        for j in range(args.batch):
+            utt = (i * args.batch + j) * world + rank
+            rng = np.random.default_rng(utt)
+            st = np.sort(rng.integers(0, 500, size=int(rng.integers(1, 12)))) / 50.0
+            results[utt] = (st, st + 0.02)
+    cpu = torch.device("cpu")
+    merged = shard.allgather_results(results, device=cpu)
+    counters = shard.allreduce_counters(len(results), len(results), len(results), device=cpu)
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    assert len(merged) == world * args.steps * args.batch and counters[0] == len(merged)
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        total = world * args.batch * args.steps
+        print(json.dumps({"metric": METRIC, "value": total / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": "DRY RUN: fabricated word times, no GPU work (harness rehearsal only; not a measurement)",
+                                     "dist_ranks": dist.get_world_size() if dist is not None else 1,
+                                     "dist_backend": dist.get_backend() if dist is not None else None, "collated_utterances": len(merged),
+                                     "collective_calls": dict(shard.COLLECTIVE_CALLS)},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
 
 
 def build_inputs(syn, tok_mod, retok, args, n_batches, rank, world, device):
@@ -334,10 +416,12 @@ def git_head():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
     # WCA_FORCE_DIST=1 with one rank: the RCCL collation path (process group, GPU all-gathers, barriers) exactly as at N > 1, so that
@@ -347,10 +431,19 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         backend = os.environ.get("WCA_DIST_BACKEND", "nccl")  # "gloo": rehearsal of the N>1 path on a 1-GPU box
+        if backend == "nccl" and args.dry_run:
+            raise SystemExit("--dry-run has no GPU: set WCA_DIST_BACKEND=gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    if dist is not None and dist.get_world_size() != args.gpus:
+        raise SystemExit("the process group has %d ranks, --gpus asked for %d" % (dist.get_world_size(), args.gpus))
+    if args.dry_run:
+        dry_run(args, dist, rank, world)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     if os.environ.get("WCA_DIST_BACKEND", "nccl") != "nccl":
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
@@ -468,6 +561,9 @@ def main():
                        "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world,
                        "streams": "one (no overlap)" if args.no_overlap else "phase 1 / phase 2 overlapped on two streams",
                        "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region",
+                       "dist_ranks": dist.get_world_size() if dist is not None else 1,
+                       "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
+                       "collated_utterances": len(merged), "collective_calls": dict(shard.COLLECTIVE_CALLS),
                        "pipeline_tflops": total_utts * 1.356 / elapsed, "commit": git_head()},
             "roofline": {"bound": "mfma", "kernel": "%s, M=%d d=%d" % (SITE_SYMBOL[dom], args.batch * 1500, d),
                          "selected_as": "largest total time of the encoder kernel sites over the sampled steps of the timed region (every 8th step + the last: %d steps)" % sampled_steps,

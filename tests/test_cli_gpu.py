@@ -334,6 +334,10 @@ def test_bench_line_contract_and_rccl_collation_path():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["scaling"] == "weak" and d["dtype"] == "f16" and d["value"] > 0
+    # the packed-record all-gathers (sizes + buffers) and the counter all-reduce really ran on RCCL with this one rank
+    cfg = d["config"]
+    assert cfg["dist_ranks"] == 1 and cfg["dist_backend"].startswith("nccl") and cfg["collated_utterances"] == 16
+    assert cfg["collective_calls"]["all_gather"] == 2 and cfg["collective_calls"]["all_reduce"] == 1, cfg
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0

@@ -97,3 +97,62 @@ def test_pack_roundtrip_and_single_process_paths():
     idx0 = shard.shard_indices(6, 0, 2, lengths=[1, 9, 3, 7, 5, 2])
     idx1 = shard.shard_indices(6, 1, 2, lengths=[1, 9, 3, 7, 5, 2])
     assert idx0 == [1, 4, 5] and idx1 == [3, 2, 0]
+
+
+def _bench(args, env_extra):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_n_self_launches_n_ranks():
+    """`python bench.py --gpus 2` run plainly (the driver's command shape, WORLD_SIZE unset) must start 2 ranks itself, run the
+    product's collation over the process group and print exactly ONE line with n_gpus == 2 (gloo + --dry-run: no GPU here)."""
+    r, recs = _bench(["--gpus", "2", "--steps", "3", "--batch", "5", "--warmup", "0", "--dry-run"], {"WCA_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert len(recs) == 1, r.stdout
+    d = recs[0]
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["scaling"] == "weak"
+    cfg = d["config"]
+    assert cfg["dist_ranks"] == 2 and cfg["dist_backend"] == "gloo" and cfg["collated_utterances"] == 2 * 3 * 5
+    assert cfg["collective_calls"]["all_gather"] == 2 and cfg["collective_calls"]["all_reduce"] == 1
+
+
+def test_bench_gpus_n_refuses_when_devices_are_missing():
+    """RCCL needs one device per rank: with fewer than N GPUs visible the launcher must fail loudly, not benchmark one GPU and
+    label it (this container has none)."""
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("two GPUs visible")
+    r, recs = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0"], {})
+    assert r.returncode != 0 and not recs
+    assert "GPU(s) visible" in r.stderr
+
+
+def test_force_dist_keeps_the_collectives_for_one_rank(monkeypatch):
+    """WCA_FORCE_DIST=1: a single rank still runs all-gather / all-reduce (the GPU test drives exactly this over RCCL)."""
+    shard = importlib.import_module("whisper-char-alignment_amd.shard")
+    monkeypatch.setenv("WCA_FORCE_DIST", "1")
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("MASTER_PORT", str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        before = dict(shard.COLLECTIVE_CALLS)
+        res = {3: (np.array([0.1, 0.5]), np.array([0.5, 0.9])), 0: (np.zeros(0), np.zeros(0))}
+        back = shard.allgather_results(res, device=torch.device("cpu"))
+        assert sorted(back) == [0, 3] and np.array_equal(back[3][1], res[3][1])
+        assert shard.allreduce_counters(1, 2, 3, device=torch.device("cpu")) == (1, 2, 3)
+        assert shard.COLLECTIVE_CALLS["all_gather"] == before["all_gather"] + 2
+        assert shard.COLLECTIVE_CALLS["all_reduce"] == before["all_reduce"] + 1
+        monkeypatch.delenv("WCA_FORCE_DIST")
+        shard.allgather_results(res, device=torch.device("cpu"))
+        assert shard.COLLECTIVE_CALLS["all_gather"] == before["all_gather"] + 2   # passthrough again
+    finally:
+        dist.destroy_process_group()

@@ -4,8 +4,22 @@ collation talks: one all-gather of packed per-utterance results and one all-redu
 evaluation counters the reference accumulates serially (infer_ali.py:53-55,123-132).
 On MI355X the backend is "nccl" (= RCCL over xGMI); the same code runs over "gloo" in CPU tests.
 """
+import os
+
 import numpy as np
 import torch
+
+
+# collectives actually issued by this process (bench.py reports them: proof that the RCCL path ran, not the passthrough)
+COLLECTIVE_CALLS = {"all_gather": 0, "all_reduce": 0, "gather_object": 0}
+
+
+def _single_process(dist):
+    """No process group, or one rank: nothing to exchange. WCA_FORCE_DIST=1 keeps the collectives even for one rank, so that the
+    RCCL all-gather / all-reduce path itself can be exercised on a 1-GPU box."""
+    if not dist.is_available() or not dist.is_initialized():
+        return True
+    return dist.get_world_size() == 1 and os.environ.get("WCA_FORCE_DIST") != "1"
 
 
 def shard_indices(n_items, rank, world, lengths=None):
@@ -51,7 +65,7 @@ def allgather_results(local_results, device=None):
     """Collates every rank's {utt_index: (starts, ends)} on all ranks. Two collectives: an all-gather of
     the packed byte counts, then one all-gather of the buffers padded to the maximum count."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single_process(dist):
         return dict(local_results)
     world = dist.get_world_size()
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
@@ -59,6 +73,7 @@ def allgather_results(local_results, device=None):
     packed = torch.from_numpy(pack_results(local_results)).to(dev)
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, torch.tensor([packed.numel()], dtype=torch.int64, device=dev))
+    COLLECTIVE_CALLS["all_gather"] += 2
     mx = int(sizes.max().item())
     padded = torch.zeros(max(mx, 1), dtype=torch.uint8, device=dev)
     padded[:packed.numel()] = packed
@@ -74,12 +89,13 @@ def allgather_results(local_results, device=None):
 def allreduce_counters(corrects, total_preds, total_gts, device=None):
     """Sums the evaluation counters over ranks (they are plain python ints in the reference)."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single_process(dist):
         return corrects, total_preds, total_gts
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl"
                                              else torch.device("cpu"))
     t = torch.tensor([corrects, total_preds, total_gts], dtype=torch.int64, device=dev)
     dist.all_reduce(t)
+    COLLECTIVE_CALLS["all_reduce"] += 1
     return tuple(int(v) for v in t.tolist())
 
 
@@ -88,11 +104,12 @@ def gather_predictions(local_predictions, dst=0):
     infer_ali.py:118-119) merged on rank `dst` (returns None on the other ranks). The reference is single-process; with
     one rank per GPU each rank only holds its shard, and eval_ali.py must see the whole corpus."""
     import torch.distributed as dist
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    if _single_process(dist):
         return dict(local_predictions)
     rank, world = dist.get_rank(), dist.get_world_size()
     bucket = [None] * world if rank == dst else None
     dist.gather_object(dict(local_predictions), bucket, dst=dst)
+    COLLECTIVE_CALLS["gather_object"] += 1
     if rank != dst:
         return None
     merged = {}
