@@ -393,3 +393,15 @@ def test_bench_conditioning_probe_separates_sharp_from_flat_matrices():
         ti, tj = timing_ref.dtw(-m)
         st, en = timing_ref.jumps_to_times(ti, tj, wt)
         assert bench.oracle_is_ill_conditioned(m, tt, st, en) is expect
+
+
+def test_alignment_head_tables_equal_the_published_masks():
+    """engine.ALIGNMENT_HEADS (index lists used by from_checkpoint(name=) / --default_whisper_timing) against the upstream
+    package's own base85 + gzip masks: every string must decompress (the gzip CRC-32 pins it byte for byte) to a
+    [n_text_layer, n_text_head] boolean mask whose row-major true positions are exactly the list."""
+    eng = importlib.import_module("whisper-char-alignment_amd.engine")
+    assert set(eng.ALIGNMENT_HEADS_B85) | {"large"} == set(eng.ALIGNMENT_HEADS)
+    for name, dump in eng.ALIGNMENT_HEADS_B85.items():
+        d = eng.dims_for(name)
+        assert eng.decode_alignment_heads(dump, d.n_text_layer, d.n_text_head) == eng.ALIGNMENT_HEADS[name], name
+    assert eng.ALIGNMENT_HEADS["large"] == eng.ALIGNMENT_HEADS["large-v3"]

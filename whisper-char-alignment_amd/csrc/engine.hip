@@ -164,10 +164,15 @@ struct wca_engine {
   float* sk_part[2] = {nullptr, nullptr};  // split-K workspaces of the few-row GEMM (one per decode stream) and their
   unsigned* sk_cnt[2] = {nullptr, nullptr};  // arrival counters (zero at creation, self-cleaning)
   size_t sk_floats = 0, sk_tiles = 0;
-  float* sk_big[2] = {nullptr, nullptr};   // split-K partials of the 128 x 128 tile GEMM (small batches: fc2), [0] encoder stream, [1] decoder
+  float* sk_big[3] = {nullptr, nullptr, nullptr};   // split-K partials of the 128 x 128 tile GEMM (small batches: fc2): [0] encoder stream,
+                                                     // [1 + ws] decoder / decode stream ws (the two half-batches of the decode loop may run it concurrently)
   size_t sk_big_bytes = 0;
   int n_cu = 0;
-  int* err_dev = nullptr;    // device flag raised by kernels: bit 0 token id outside the vocabulary, bit 1 LayerNorm hand-off timeout
+  int* err_dev = nullptr;    // device flags raised by kernels. Word 0: phase 2 / synchronous entry points (bit 0 token id outside the
+                             // vocabulary, bit 1 LayerNorm hand-off timeout); words 1, 2: phase 1 of the batch in cross-K/V slot 0, 1 (bit 1
+                             // only), cleared on `stream` before that batch's encoder and read with the batch's results, so that neither the
+                             // phase-2 clear of this batch nor the next batch's encoder (concurrent on `stream`) can wipe or alias it
+  int* ln_err = nullptr;     // where the encoder's out_mode-3 GEMMs raise their time-out bit (err_dev, or err_dev + 1 + slot in run_phase1)
   int* err_host = nullptr;   // pinned: read back by the synchronous entry points
 
   // ---- run-time sized buffers
@@ -194,11 +199,11 @@ struct wca_engine {
 
   hipEvent_t ev[9] = {};
   // start/stop pairs around each kernel of every encoder layer (profiling only): site = WCA_SITE_* of include/wca.h
-  hipEvent_t kev[WCA_N_SITES][32][2] = {};
-  bool kev_set[WCA_N_SITES][32] = {};   // which (site, layer) pairs the last encoder run recorded
+  hipEvent_t kev[WCA_N_SITES][33][2] = {};   // slot 32: ln_post of a 32-layer encoder (site LN1, slot n_layer)
+  bool kev_set[WCA_N_SITES][33] = {};   // which (site, layer) pairs the last encoder run recorded
   bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
-  bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= 256 rows (wca_set_decode_mode)
+  bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
                              // back to back, not concurrently -- 3.86 vs 3.90 ms per step -- so one stream is the default)
   bool ev_valid = false;
@@ -322,7 +327,7 @@ size_t layout_arena(wca_engine* e, char* base) {
     }
     // 128 x 128 tile GEMM with at most n_cu / 2 = 128 tiles, 4 K slices of f32 partials
     e->sk_big_bytes = (size_t)4 * 128 * 128 * 128 * sizeof(float);
-    for (int i = 0; i < 2; ++i) e->sk_big[i] = carve<float>(cur, e->sk_big_bytes / sizeof(float));
+    for (int i = 0; i < 3; ++i) e->sk_big[i] = carve<float>(cur, e->sk_big_bytes / sizeof(float));
   }
   return (size_t)(cur - base) + 4096;
 }
@@ -395,7 +400,7 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
     A = xn_scratch;
     lda = K;
   }
-  HIPCHK(gemm(s, A, lda, W, ldw, bias, C, ldc, M, N, K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes));
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, C, ldc, M, N, K, gelu, out_mode, site, e->sk_big[1 + ws], e->sk_big_bytes));
   if (kv_k) HIPCHK(launch_kv_append(reinterpret_cast<const half_t*>(C), kv_k, kv_v, M, T_max, kv_t, N / 3, s));
   return WCA_OK;
 }
@@ -409,7 +414,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
                      int K, const float* gamma, const float* beta, half_t* xn, int site, bool allow_fused = true, int ev_gemm_site = -1,
                      int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0) {
   auto ev = [&](int st, int li, int which) {
-    if (e->profiling && st >= 0 && li >= 0 && li < 32) {
+    if (e->profiling && st >= 0 && li >= 0 && li < 33) {
       (void)hipEventRecord(e->kev[st][li][which], s);
       e->kev_set[st][li] = true;
     }
@@ -436,7 +441,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     g.ln_eps = 1e-5f;
     g.ln_stats = e->ln_stats;
     g.ln_cnt = e->ln_cnt;
-    g.ln_err = e->err_dev;
+    g.ln_err = e->ln_err ? e->ln_err : e->err_dev;
     HIPCHK(launch_gemm(g, s));
     ev(ev_gemm_site, ev_gemm_li, 1);
     return WCA_OK;
@@ -590,7 +595,7 @@ int run_encoder(wca_engine* e, int B) {
   const float scale = 1.0f / std::sqrt((float)(d / H));
   memset(e->kev_set, 0, sizeof(e->kev_set));
   auto mark = [&](int site, int li, int which) {
-    if (e->profiling && li < 32) {
+    if (e->profiling && li < 33) {
       (void)hipEventRecord(e->kev[site][li][which], s);
       e->kev_set[site][li] = true;
     }
@@ -894,7 +899,10 @@ int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_
     HIPCHK(hipGetLastError());
   }
   record(e, 1);
+  e->ln_err = e->err_dev + 1 + slot;
+  HIPCHK(hipMemsetAsync(e->ln_err, 0, sizeof(int), e->stream));
   int rc = run_encoder(e, batch);
+  e->ln_err = e->err_dev;
   if (rc) return rc;
   record(e, 2);
   rc = run_cross_kv(e, batch, kvbuf, skip_last_v);
@@ -1166,7 +1174,7 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   HIPCHK(hipEventSynchronize(e->ev[8]));
   int nl = 0;
   float tot = 0.f;
-  for (int i = 0; i < 32; ++i) {
+  for (int i = 0; i < 33; ++i) {
     if (!e->kev_set[site][i]) continue;
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, e->kev[site][i][0], e->kev[site][i][1]));
@@ -1765,8 +1773,9 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   int* rows[4];
   // (re-use: the metadata is only read by phase 2, so it travels on that stream -- `stream` may already hold the next
   // batch's phase 1, and an event recorded behind it would serialise this batch's phase 2 after it)
+  hipStream_t s2 = e->overlap ? e->stream2 : e->stream;  // the stream phase 2 runs on
   rc = stage_meta(e, batch, reuse_enc ? nullptr : n_samples_host, n_tok_host, max_frames_host, dn.data(), rows,
-                  reuse_enc ? e->stream2 : nullptr);
+                  reuse_enc ? s2 : nullptr);
   if (rc) return rc;
   // ---- phase 1 on `stream`: log-mel, encoder, cross-K/V of all decoder layers into a free K/V slot (a slot is busy
   // from its encode until the alignment that read it has been fetched; at most 2 alignments are in flight), or the
@@ -1790,7 +1799,6 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
     }
   }
   half_t* kvbuf = bs ? e->kv_alt : e->kv;
-  hipStream_t s2 = e->overlap ? e->stream2 : e->stream;
   // ---- phase 2 on `stream2`: decoder with capture, head statistics, top-k, aggregation, DTW, D2H. These are
   // latency-bound kernels with few workgroups; on their own stream they overlap the NEXT batch's phase 1.
   HIPCHK(hipStreamWaitEvent(s2, e->ev_kv[bs], 0));
@@ -1838,10 +1846,13 @@ int wca_align_batch_enqueue(wca_engine* e, const float* pcm_dev, int64_t pcm_str
   // results -> pinned staging (ring of 2 so the host can post-process batch i while batch i+1 runs)
   const int k = o->aggregation == WCA_AGGR_TOPK ? o->topk : 0;
   const int rs = (int)(e->enq_count & 1);
-  rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1) + 1);
+  rc = ensure_res_host(e, rs, (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1) + 2);
   if (rc) return rc;
-  // the invalid-token flag of this batch travels with its results (last int of the staging slot)
+  // the flags of this batch travel with its results (last two ints of the staging slot): phase 2's word, and the word phase 1
+  // raised for this batch's cross-K/V slot (complete: s2 waited for ev_kv[bs], recorded behind that encoder)
   HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1), e->err_dev, sizeof(int),
+                        hipMemcpyDeviceToHost, s2));
+  HIPCHK(hipMemcpyAsync(e->res_host[rs] + (size_t)batch * n_tok_max + (size_t)batch * (k > 0 ? k : 1) + 1, e->err_dev + 1 + bs, sizeof(int),
                         hipMemcpyDeviceToHost, s2));
   if (n_tok_max - o->sot_len - 1 >= 1)
     HIPCHK(hipMemcpyAsync(e->res_host[rs], e->jump.p, sizeof(int) * (size_t)batch * n_tok_max, hipMemcpyDeviceToHost, s2));
@@ -2058,7 +2069,8 @@ int wca_align_batch_fetch(wca_engine* e, int batch, int n_tok_max, int topk, int
   e->res_kvslot[rs] = -1;
   e->fetch_count++;
   const int kk = e->res_topk[rs];
-  const int flag = e->res_host[rs][(size_t)batch * n_tok_max + (size_t)batch * (kk > 0 ? kk : 1)];
+  const size_t fo = (size_t)batch * n_tok_max + (size_t)batch * (kk > 0 ? kk : 1);
+  const int flag = e->res_host[rs][fo] | (e->res_host[rs][fo + 1] & 2);
   if (flag & 2) return fail(WCA_ERR_HIP, "LayerNorm statistics hand-off timed out inside a GEMM epilogue (a workgroup of a row panel never arrived)");
   if (flag)
     return fail(WCA_ERR_INVALID, "a token id is outside the model's vocabulary [0, %d) (tokenizer / checkpoint mismatch?)", e->dims.n_vocab);

@@ -77,19 +77,22 @@ uint8_t crc8(const uint8_t* d, size_t n) {
   return c;
 }
 
-uint16_t crc16(const uint8_t* d, size_t n) {
-  static uint16_t table[256];
-  static bool init = false;
-  if (!init) {
+// built once, thread-safe (C++11 magic static): the decoder is called from several reader threads at once
+struct Crc16Table {
+  uint16_t t[256];
+  Crc16Table() {
     for (int i = 0; i < 256; ++i) {
       uint16_t c = (uint16_t)(i << 8);
       for (int b = 0; b < 8; ++b) c = (c & 0x8000) ? (uint16_t)((c << 1) ^ 0x8005) : (uint16_t)(c << 1);
-      table[i] = c;
+      t[i] = c;
     }
-    init = true;
   }
+};
+
+uint16_t crc16(const uint8_t* d, size_t n) {
+  static const Crc16Table table;
   uint16_t c = 0;
-  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table[((c >> 8) ^ d[i]) & 0xff]);
+  for (size_t i = 0; i < n; ++i) c = (uint16_t)((c << 8) ^ table.t[((c >> 8) ^ d[i]) & 0xff]);
   return c;
 }
 

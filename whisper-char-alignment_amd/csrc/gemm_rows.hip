@@ -1,5 +1,5 @@
 // Few-row GEMM of the greedy ASR pre-pass (one decode step: M = batch rows; reference call sites infer_ali.py:40,60-61
-// `whisper.decode`) and of small teacher-forced forwards (M <= 256): C[m][n] = epilogue(sum_k A[m][k] * W[n][k]).
+// `whisper.decode`) and of small teacher-forced forwards (M <= 128 rows, DEC_ROWS_MAX): C[m][n] = epilogue(sum_k A[m][k] * W[n][k]).
 //
 // These launches are latency-bound (a step is ~290 dependent kernels of 5-20 us), so the kernel is built to (1) take
 // neighbouring small kernels INTO the GEMM and (2) have every weight byte in flight from the first instruction:

@@ -57,8 +57,34 @@ def dims_for(name):
 
 # openai-whisper's per-model alignment heads (`whisper._ALIGNMENT_HEADS`, applied by whisper.load_model(name) through
 # set_alignment_heads): the (layer, head) pairs of the decoder cross-attention heads highly correlated with word timing.
-# Published data of the upstream package (there it is stored as base85 + gzip boolean masks); these are the decoded
-# index lists, row-major like `model.alignment_heads.indices().T` (timing.py:155).
+# Published data of the upstream package, kept here in BOTH forms: the package's own base85 + gzip boolean masks
+# (ALIGNMENT_HEADS_B85, decoded by decode_alignment_heads exactly like whisper.model.Whisper.set_alignment_heads:
+# b85decode -> gzip -> bool[n_text_layer, n_text_head]) and the decoded index lists, row-major like
+# `model.alignment_heads.indices().T` (timing.py:155). tests/test_host.py decodes every mask (the gzip CRC-32 validates each
+# string byte for byte) and requires it to equal the list below.
+ALIGNMENT_HEADS_B85 = {
+    "tiny.en": b"ABzY8J1N>@0{>%R00Bk>$p{7v037`oCl~+#00",
+    "tiny": b"ABzY8bu8Lr0{>%RKn9Fp%m@SkK7Kt=7ytkO",
+    "base.en": b"ABzY8;40c<0{>%RzzG;p*o+Vo09|#PsxSZm00",
+    "base": b"ABzY8KQ!870{>%RzyTQH3`Q^yNP!>##QT-<FaQ7m",
+    "small.en": b"ABzY8>?_)10{>%RpeA61k&I|OI3I$65C{;;pbCHh0B{qLQ;+}v00",
+    "small": b"ABzY8DmU8=0{>%Rpa?J`kvJ6qF(V^F86#Xh7JUGMK}P<N0000",
+    "medium.en": b"ABzY8usPae0{>%R7<zz_OvQ{)4kMa0BMw6u5rT}kRKX;$NfYBv00*Hl@qhsU00",
+    "medium": b"ABzY8B0Jh+0{>%R7}kK1fFL7w6%<-Pf*t^=N)Qr&0RR9",
+    "large-v1": b"ABzY8r9j$a0{>%R7#4sLmoOs{s)o3~84-RPdcFk!JR<kSfC2yj",
+    "large-v2": b"ABzY8zd+h!0{>%R7=D0pU<_bnWW*tkYAhobTNnu$jnkEkXqp)j;w1Tzk)UH3X%SZd&fFZ2fC2yj",
+    "large-v3": b"ABzY8gWO1E0{>%R7(9S+Kn!D~%ngiGaR?*L!iJG9p-nab0JQ=-{D1-g00",
+}
+
+
+def decode_alignment_heads(dump, n_text_layer, n_text_head):
+    """base85 + gzip boolean mask -> [(layer, head), ...] in row-major order (whisper.model.Whisper.set_alignment_heads)."""
+    import base64
+    import gzip
+    mask = np.frombuffer(gzip.decompress(base64.b85decode(dump)), dtype=bool).reshape(n_text_layer, n_text_head)
+    return [(int(l), int(h)) for l, h in np.argwhere(mask)]
+
+
 ALIGNMENT_HEADS = {
     "tiny.en": [(1, 0), (2, 0), (2, 5), (3, 0), (3, 1), (3, 2), (3, 3), (3, 4)],
     "tiny": [(2, 2), (3, 0), (3, 2), (3, 3), (3, 4), (3, 5)],
