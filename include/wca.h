@@ -250,7 +250,9 @@ int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capa
 
 /* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
 /* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device. out_mode low byte: 0 f16 store, 1 f32 store,
- * 2 f32 accumulate; out_mode >> 8: force the tile shape (0 auto, 128, 256). */
+ * 2 f32 accumulate, 4 f16 PAIR store (split mode: c_dev is f16 [M][2N], hi = f16(v) at column n, lo = f16(v - hi) at column
+ * N + n; GELU is then the erff form); out_mode >> 8: force the tile shape (0 auto, 128, 256). A split-mode GEMM is this call
+ * with A = [A_hi | A_lo] ([M][2K]), W = [W | W] ([N][2K]) and K = 2K. */
 int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                   int N, int K, int gelu, int out_mode);
 /* x (f32 [M][N], read-modify-write) += A W^T + bias; xn (f16 [M][N]) = LayerNorm(x; gamma, beta, eps 1e-5): the residual
@@ -274,6 +276,10 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f1
  * kernel that serves the encoder's un-masked self-attention) */
 int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
                        float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
+/* split-mode attention (attention_split.hip): q2,k2,v2 [B][n][2*H*64] f16 rows [hi(H*64) | lo(H*64)] -> o2 [B][nq][2*H*64]
+ * likewise; cap_dev as above (the three-pass fp32 logits times scale). causal: bit 0 only. */
+int wca_test_attention_split(wca_engine* e, const void* q2_dev, const void* k2_dev, const void* v2_dev, void* o2_dev,
+                             float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
 /* diagnostic build with s_memtime stamps per key tile ([4 blocks][4 waves][32 tiles][8] u64); tools/attn_stamps.py */
 int wca_test_attention_stamped(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev, int B, int H,
                                int nq, int nk, unsigned long long* dbg_dev);
@@ -283,6 +289,9 @@ int wca_test_decode_select(wca_engine* e, const float* logits_dev, int batch, in
                            const wca_decode_opts* opts, float* sum_logprob_dev, int32_t* n_done_dev);
 int wca_test_layernorm(wca_engine* e, const float* x_dev, const float* g_dev, const float* b_dev, void* out_f16_dev,
                        int rows, int d);
+/* split-mode LayerNorm: out2 f16 [rows][2d], hi = f16(y) at column c, lo = f16(y - hi) at column d + c */
+int wca_test_layernorm_split(wca_engine* e, const float* x_dev, const float* g_dev, const float* b_dev, void* out2_f16_dev,
+                             int rows, int d);
 /* encoder only: mel_dev [batch][n_mels][3000] f32 -> xa_out_dev [batch][1500][d] f32 (ln_post output) */
 int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_out_dev);
 
@@ -312,6 +321,22 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
  * of a few f16 outputs per thousand). Measured at the bench configuration: -0.15 ms per encoder layer at kernel level,
  * +0.3 % end to end with the two-stream overlap, hence not the default. */
 int wca_set_fuse_ln(wca_engine* e, int on);
+/* Arithmetic of the model forward (reference: timing.py:58, `model(mel.unsqueeze(0), tokens.unsqueeze(0))` -- an fp32
+ * forward of a checkpoint whose weights are f16 at rest):
+ *   WCA_PRECISION_F16 (default): GEMM / attention operands are rounded to f16 once (11 significant bits), accumulation,
+ *     residual stream, LayerNorm, softmax and everything downstream fp32. Fastest; attention maps agree with the fp32
+ *     reference to ~3e-3, which can move an ill-conditioned DTW path or swap two near-tied heads of the top-k selection.
+ *   WCA_PRECISION_SPLIT: reference precision on the f16 matrix pipe. Every activation operand x travels as the pair
+ *     hi = f16(x), lo = f16(x - hi) (x = hi + lo to 2^-22 |x|) in one row [hi | lo]; weights are exact in f16, so
+ *     A W^T = [A_hi | A_lo] [W | W]^T is a K-doubled call of the same MFMA GEMM kernels (f16 x f16 products are exact in
+ *     the fp32 accumulator); attention runs three passes per product (hi.hi + hi.lo + lo.hi), GELU uses erff, the log-mel
+ *     DFT accumulates in f64. What is left is fp32 summation-order noise, like between two fp32 BLAS libraries. Costs
+ *     ~2.3x the MFMA work, twice the operand memory and a second copy of the weights ([N][2K]).
+ * The greedy ASR pre-pass (wca_greedy_decode) computes in f16 in both modes, like whisper.decode's fp16 default.
+ * Switching re-creates the activation arena: no batch may be in flight, encoded-but-unconsumed states are dropped. */
+enum { WCA_PRECISION_F16 = 0, WCA_PRECISION_SPLIT = 1 };
+int wca_set_precision(wca_engine* e, int mode);
+int wca_get_precision(wca_engine* e);
 /* on (default): phase 2 (decoder, post-processing, DTW) of a batch runs on the engine's second stream beside the next
  * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
  * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */

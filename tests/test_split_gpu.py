@@ -1,0 +1,289 @@
+"""Reference-precision ("split") mode on the MI355X (`-m gpu`): wca_set_precision(e, WCA_PRECISION_SPLIT) carries every GEMM /
+attention operand as an f16 (hi, lo) pair against the exact f16 weights, so the forward of timing.py:58 (`model(mel, tokens)`, an
+fp32 forward) is reproduced to fp32 summation noise on the f16 matrix pipe. Kernel level: against float64 references, with the
+tolerance of an fp32 computation (stated per test). End to end: against the fp32 CPU oracle at the bench configuration, on the
+utterances the f16-operand mode gets wrong (bench ids 10007, 10030, 10035, 10076, 10113, 10120 -- VERDICT round 2) plus ids
+100-131: scores, aggregated matrices and every word boundary."""
+import ctypes as C
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _vp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _mods():
+    m = lambda n: importlib.import_module("whisper-char-alignment_amd." + n)  # noqa: E731
+    return m("synthetic"), m("tokenizer"), m("retokenize"), m("timing"), m("audio")
+
+
+def _split(x):
+    """fp32 tensor -> [..., 2K] f16 rows [hi | lo] (what the engine's split-mode producers write)."""
+    hi = x.half()
+    lo = (x - hi.float()).half()
+    return torch.cat([hi, lo], dim=-1).contiguous()
+
+
+def _join(x2):
+    k = x2.shape[-1] // 2
+    return x2[..., :k].double() + x2[..., k:].double()
+
+
+@pytest.fixture(scope="module")
+def eng(wca):
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    dims = wca.ModelDimensions(80, 1500, 384, 6, 2, 51865, 448, 384, 6, 2)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2)
+    m.load_state_dict(syn.random_state_dict(dims, seed=1))
+    m._bind_stream()
+    return m
+
+
+# ------------------------------------------------------------------------------- kernels
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (1500, 1152, 384), (77, 130, 64), (3000, 1024, 1024), (40, 512, 512)])
+@pytest.mark.parametrize("tile", [0, 128, 256, 257])
+def test_split_gemm_is_fp32_accurate(eng, lib, wca, M, N, K, tile):
+    """[A_hi | A_lo] . [W | W]^T through the UNCHANGED GEMM kernels (K doubled) against float64: the error must be that of an
+    fp32 GEMM (a few 1e-7 of the row's |a|.|w|), three orders below the f16-operand call on the same data."""
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g) * 0.7
+    w = (torch.randn(N, K, generator=g) * 0.1).half()
+    bias = torch.randn(N, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    scale = (a.abs().double() @ w.abs().double().T).max().item()
+    a2, w2 = _split(a).cuda(), torch.cat([w, w], dim=1).contiguous().cuda()
+    bd = bias.cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a2), _vp(w2), _vp(bd), _vp(out), M, N, 2 * K, 0, 1 | (tile << 8)))
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 4e-7 * scale, (err, scale)
+    # pair output with the erf GELU (out_mode 4): hi + lo against float64 gelu, fp32 accuracy of the stored value
+    out2 = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device="cuda")
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a2), _vp(w2), _vp(bd), _vp(out2), M, N, 2 * K, 1, 4 | (tile << 8)))
+    torch.cuda.synchronize()
+    gref = torch.nn.functional.gelu(ref)
+    gerr = (_join(out2.cpu()) - gref).abs().max().item()
+    assert gerr < 4e-7 * scale + 3e-7 * gref.abs().max().item(), gerr
+    # contrast: the default mode on the f16-rounded activations
+    outh = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    ah = a.half().cuda()
+    wd = w.cuda()
+    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(ah), _vp(wd), _vp(bd), _vp(outh), M, N, K, 0, 1 | (tile << 8)))
+    torch.cuda.synchronize()
+    herr = (outh.cpu().double() - ref).abs().max().item()
+    assert herr > 20 * err, (herr, err)
+
+
+def _attn_ref64(q, k, v, H, causal):
+    B, nq, d = q.shape
+    nk = k.shape[1]
+    qh = q.double().view(B, nq, H, 64).permute(0, 2, 1, 3)
+    kh = k.double().view(B, nk, H, 64).permute(0, 2, 1, 3)
+    vh = v.double().view(B, nk, H, 64).permute(0, 2, 1, 3)
+    qk = (qh @ kh.transpose(-1, -2)) * 0.125
+    s = qk.clone()
+    if causal:
+        s = s + torch.full((nq, nk), float("-inf"), dtype=torch.float64).triu_(1)
+    o = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(B, nq, d)
+    return o, qk
+
+
+@pytest.mark.parametrize("B,H,nq,nk,causal,cap_cols", [
+    (2, 3, 150, 200, 0, 0), (1, 2, 70, 70, 1, 0), (2, 6, 69, 1500, 0, 500), (1, 4, 448, 1500, 0, 1500), (1, 2, 300, 300, 1, 0),
+    (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0), (1, 2, 97, 33, 0, 0), (3, 1, 129, 64, 1, 0), (1, 5, 2, 65, 0, 64)])
+def test_split_attention_is_fp32_accurate(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
+    """attn_split_kernel (three MFMA passes per product on hi / lo pairs, fp32 online softmax on the exact logits) against a
+    float64 attention: output and captured logits at fp32 accuracy. A few large logits exercise the running-maximum update."""
+    g = torch.Generator().manual_seed(nq * 13 + nk)
+    d = H * 64
+    q = torch.randn(B, nq, d, generator=g)
+    k = torch.randn(B, nk, d, generator=g)
+    v = torch.randn(B, nk, d, generator=g)
+    q[:, nq // 2, :64] *= 4.0
+    if nk > 700:
+        k[:, 650, :64] = q[:, nq // 2, :64] * 0.5   # a late key far above everything before it: forced rescale at key tile 10
+    # the kernel sees hi + lo of each operand; the reference takes exactly those values
+    q2, k2, v2 = _split(q), _split(k), _split(v)
+    o_ref, qk_ref = _attn_ref64(_join(q2), _join(k2), _join(v2), H, causal)
+    out2 = torch.full((B, nq, 2 * d), float("nan"), dtype=torch.float16, device="cuda")
+    cap_ld = (cap_cols + 3) & ~3
+    cap = torch.full((B, H, nq, max(cap_ld, 4)), float("nan"), device="cuda") if cap_cols else None
+    qd, kd, vd = q2.cuda(), k2.cuda(), v2.cuda()
+    wca._lib.check(lib.wca_test_attention_split(eng._h, _vp(qd), _vp(kd), _vp(vd), _vp(out2), _vp(cap), cap_ld, cap_cols, B, H, nq, nk, causal))
+    torch.cuda.synchronize()
+    got = _join(out2.cpu())
+    assert torch.isfinite(got).all()
+    err = (got - o_ref).abs().max().item()
+    assert err < 3e-6, err            # |o| <= max |v| ~ 4; fp32 softmax + 2^-22 operand pairs
+    if cap_cols:
+        cerr = (cap.cpu()[..., :cap_cols].double() - qk_ref[..., :cap_cols]).abs().max().item()
+        assert cerr < 4e-7 * qk_ref.abs().max().item() + 1e-6, cerr
+
+
+def test_split_layernorm_pairs(eng, lib, wca):
+    g = torch.Generator().manual_seed(3)
+    for d in (384, 1024, 1280):
+        x = torch.randn(37, d, generator=g) * 3 + 1
+        gm, bt = torch.randn(d, generator=g), torch.randn(d, generator=g)
+        out2 = torch.empty(37, 2 * d, dtype=torch.float16, device="cuda")
+        xd, gd, bd = x.cuda(), gm.cuda(), bt.cuda()
+        wca._lib.check(lib.wca_test_layernorm_split(eng._h, _vp(xd), _vp(gd), _vp(bd), _vp(out2), 37, d))
+        torch.cuda.synchronize()
+        ref = torch.nn.functional.layer_norm(x.double(), (d,), gm.double(), bt.double(), 1e-5)
+        assert (_join(out2.cpu()) - ref).abs().max().item() < 3e-6
+
+
+# ------------------------------------------------------------------------------- forward against the fp32 oracle
+def _utt(syn, rt, tok, uid, n_samples, n_chars):
+    pcm = syn.synth_audio(uid, n_samples)
+    text = syn.synth_text(uid, n_chars)
+    tt = rt.encode(text, tok, "char")
+    return pcm, text, tt, [*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]
+
+
+def test_split_forward_vs_oracle_small_dims(wca):
+    """Small model (256 wide, 3 + 3 layers): log-mel, encoder output, softmaxed maps, logits and word times of the split mode
+    against the fp32 CPU oracle, with the tolerances of two fp32 implementations of the same forward -- 100-1000x tighter than
+    the default mode's (test_e2e_gpu.py) -- and the mode switch itself (f16 -> split -> f16 gives the first result again)."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
+    sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
+    ref = whisper_ref.WhisperRef(sd, dims)
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 7, 80000, 40)
+    F = len(pcm) // 320
+    mel16 = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    w16, _ = tm.get_attentions(mel16, torch.tensor(tokens).cuda(), model, tok, F, medfilt_width=3)
+    assert model.precision == "f16"
+    model.set_precision("split")
+    assert model.precision == "split"
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    ref_mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), audio.mel_filters(80))
+    mel_err = (mel.cpu() - ref_mel).abs().max().item()
+    enc = model.encode(ref_mel[None].cuda()).cpu()[0]
+    renc = ref.encoder(ref_mel[None])[0]
+    enc_err = (enc - renc).abs().max().item()
+    w, logits = tm.get_attentions(ref_mel.cuda(), torch.tensor(tokens).cuda(), model, tok, F, medfilt_width=3)
+    rw, rlogits = timing_ref.get_attentions(ref_mel, torch.tensor(tokens), ref, F, 3, 1.0)
+    w_err = (w.cpu() - rw).abs().max().item()
+    l_err = ((logits.cpu() - rlogits).abs().max() / rlogits.abs().max()).item()
+    w16_err = (w16.cpu() - rw).abs().max().item()
+    print("split vs oracle: log-mel %.2e, encoder %.2e, maps %.2e (f16 mode %.2e), logits %.2e rel" % (mel_err, enc_err, w_err, w16_err, l_err))
+    assert mel_err < 2e-5
+    assert enc_err < 5e-5          # LayerNorm-ed outputs, O(1)
+    assert w_err < 5e-6            # softmaxed maps in [0, 1]
+    assert l_err < 2e-5
+    words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=4)
+    rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 4)
+    assert words == rwords and np.array_equal(st, rst) and np.array_equal(en, ren)
+    assert [lh for _, lh, _ in scores] == [lh for _, lh, _ in rscores]
+    assert max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(scores, rscores)) < 1e-5
+    # fused batch path in split mode == the step-by-step API in split mode (ragged batch)
+    specs = [(31, 48000, 25), (32, 80000, 40), (33, 32000, 12)]
+    utts = [_utt(syn, rt, tok, u, n, c) for u, n, c in specs]
+    n_max, smax = max(len(u[3]) for u in utts), max(len(u[0]) for u in utts)
+    pb = np.zeros((3, smax), dtype=np.float32)
+    tarr = np.full((3, n_max), tok.eot, dtype=np.int64)
+    for i, (p, _, _, toks) in enumerate(utts):
+        pb[i, :len(p)] = p
+        tarr[i, :len(toks)] = toks
+    n_samples, n_tok, frames = [len(u[0]) for u in utts], [len(u[3]) for u in utts], [len(u[0]) // 320 for u in utts]
+    opts = model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3)
+    jump, sel = model.align_batch(torch.from_numpy(pb).cuda(), n_samples, torch.from_numpy(tarr).cuda(), n_tok, frames, opts)
+    for i, (p, text_i, tt_i, toks) in enumerate(utts):
+        rmel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(p)), audio.mel_filters(80))
+        rw_i, _ = timing_ref.get_attentions(rmel, torch.tensor(toks), ref, frames[i], 3, 1.0)
+        _rw, rst_i, ren_i, _m, rsc_i = timing_ref.force_align(rw_i, tt_i, rtok, "char", "topk", 4)
+        _w2, st2, en2 = tm.words_from_jump_frames(jump[i], tt_i, tok, "char")
+        assert np.array_equal(st2, rst_i) and np.array_equal(en2, ren_i), (i, st2, rst_i)
+        assert list(sel[i]) == [l * dims.n_text_head + h for _, (l, h), _ in rsc_i]
+    # back to the default mode: the arena is re-created, the result is the first one again
+    model.set_precision("f16")
+    w16b, _ = tm.get_attentions(mel16, torch.tensor(tokens).cuda(), model, tok, F, medfilt_width=3)
+    assert torch.equal(w16b, w16)
+    del model
+
+
+OFFENDER_IDS = [10007, 10030, 10035, 10076, 10113, 10120]   # outside one frame in the f16-operand mode (profiles/r02_parity_leg_128utt.json)
+
+
+def test_split_mode_closes_the_headline_parity_gap(wca):
+    """The bench configuration (whisper-medium dims, peaky seeded weights, 10 s audio, 64 chars, top-10, medfilt 3) through the
+    FUSED wca_align_batch at B = 64 in split mode, on the six utterances the f16-operand mode puts outside the tolerance plus the
+    ids 100-131 of test_north_star_config_parity_medium_dims, against the fp32 CPU oracle:
+      * every word boundary within one 20 ms frame -- except where the ORACLE's own k-th / (k+1)-th selection scores are closer
+        than the measured score deviation (such a tie is decided by fp32 summation order in any implementation);
+      * selection scores and aggregated matrix of the step-by-step API within 1e-5 / 2e-5 relative of the oracle's.
+    The same batch in the default mode is run for contrast (its offenders are printed, not asserted)."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    B = 64
+    ids = OFFENDER_IDS + list(range(100, 132))
+    fill = (ids * ((B + len(ids) - 1) // len(ids)))[:B]
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    utts = [_utt(syn, rt, tok, u, 160000, 64) for u in fill]
+    pcm = np.stack([u[0] for u in utts])
+    tarr = np.asarray([u[3] for u in utts], dtype=np.int64)
+    opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
+    args = (torch.from_numpy(pcm).cuda(), [160000] * B, torch.from_numpy(tarr).cuda(), [69] * B, [500] * B, opts)
+    jump16, sel16 = model.align_batch(*args)
+    model.set_precision("split")
+    jump, sel = model.align_batch(*args)
+    H, LH = dims.n_text_head, dims.n_text_layer * dims.n_text_head
+    total = ident = 0
+    off_split, off_f16, excused = [], [], []
+    max_dscore = max_dmatrix = 0.0
+    for i, uid in enumerate(ids):
+        p, text, tt, tokens = utts[i]
+        mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(p)), audio.mel_filters(80))
+        rw, _ = timing_ref.get_attentions(mel, torch.tensor(tokens), ref, 500, 3, 1.0)
+        rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
+        allref = sorted(s_ for s_, _lh, _n in timing_ref.filter_attention(rw, LH)[1])
+        gap = (allref[-10] - allref[-11]) / abs(allref[-10])     # relative distance of the oracle's 10th and 11th head
+        for jj, store in ((jump, off_split), (jump16, off_f16)):
+            words, st, en = tm.words_from_jump_frames(jj[i], tt, tok, "char")
+            assert words == rwords
+            n_off = int(np.sum(np.abs(np.asarray(st) - rst) > 0.02 + 1e-9) + np.sum(np.abs(np.asarray(en) - ren) > 0.02 + 1e-9))
+            if jj is jump:
+                total += 2 * len(st)
+                ident += int((np.asarray(st) == rst).sum() + (np.asarray(en) == ren).sum())
+            if n_off:
+                store.append((uid, n_off, gap))
+        if uid in OFFENDER_IDS:
+            # step-by-step API in split mode on the utterance alone: scores and matrix against the oracle's
+            w, _ = tm.get_attentions(mel.cuda(), torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
+            _wd, _s, _e, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=10)
+            gs = {lh: s_ for s_, lh, _n in tm.filter_attention(w, LH)[1]}
+            rs = {lh: s_ for s_, lh, _n in timing_ref.filter_attention(rw, LH)[1]}
+            dscore = max(abs(gs[lh] - rs[lh]) / abs(rs[lh]) for lh in rs)
+            max_dscore = max(max_dscore, dscore)
+            if [lh for _, lh, _ in scores] == [lh for _, lh, _ in rscores]:
+                dm = ((matrix.cpu() - rmatrix).norm() / rmatrix.norm()).item()
+                max_dmatrix = max(max_dmatrix, dm)
+            print("utt %d: oracle 10th/11th score gap %.2e, max rel score deviation %.2e" % (uid, gap, dscore))
+    print("split mode, medium B=64 fused: %d boundaries over %d utterances, identical %d, utterances with a boundary outside one frame: split %s | f16 %s; "
+          "max rel |dscore| %.2e, rel |dmatrix| %.2e" % (total, len(ids), ident, off_split, off_f16, max_dscore, max_dmatrix))
+    assert max_dscore < 1e-5, max_dscore
+    assert max_dmatrix < 2e-5, max_dmatrix
+    # a miss is only acceptable where the oracle itself is tied at the selection cut below the measured score noise
+    for uid, n_off, gap in off_split:
+        if gap < 4 * max(max_dscore, 1e-6):
+            excused.append(uid)
+    bad = [o for o in off_split if o[0] not in excused]
+    assert not bad, (bad, excused)
+    del model

@@ -77,14 +77,18 @@ SIGNATURES = {
     "wca_test_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
+    "wca_test_attention_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_stamped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
+    "wca_test_layernorm_split": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "wca_test_encoder": (_i, [_vp, _vp, _i, _vp]),
     "wca_last_stage_ms": (_i, [_vp, _pf]),
     "wca_set_profiling": (_i, [_vp, _i]),
     "wca_last_kernel_ms": (_i, [_vp, _i, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wca_set_overlap": (_i, [_vp, _i]),
     "wca_set_fuse_ln": (_i, [_vp, _i]),
+    "wca_set_precision": (_i, [_vp, _i]),
+    "wca_get_precision": (_i, [_vp]),
     "wca_set_decode_mode": (_i, [_vp, _i, _i]),
     "wca_probe_strict_tp": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_double, _vp]),
     "wca_test_gemm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),

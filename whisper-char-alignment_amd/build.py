@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwca.so")
-SOURCES = ["gemm.hip", "gemm_rows.hip", "attention.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip", "flac.cpp"]
+SOURCES = ["gemm.hip", "gemm_rows.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip", "flac.cpp"]
 HEADERS = ["kernels.h", "wca_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "wca.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (the softmax / epilogue VALU code reads them
 # directly; the AGPR form costs a v_accvgpr_read/write pair per element in the attention loop)

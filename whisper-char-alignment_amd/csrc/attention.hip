@@ -813,6 +813,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnArgs a) {
 }  // namespace
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+  if (a.split) return launch_attention_split(a, s);  // reference-precision mode: hi/lo operand pairs, three MFMA passes
   if (a.nq <= 0 || a.B <= 0) return hipSuccess;
   if (a.nk <= 0) return hipErrorInvalidValue;
   if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;

@@ -1,0 +1,328 @@
+// Reference-precision ("split") attention for gfx950, head_dim 64: the attention of attention.hip's attn_kernel with every f16
+// operand carried as a PAIR (hi = f16(x), lo = f16(x - hi), x = hi + lo to 2^-22) and each product as three MFMA passes:
+//     S   = Qhi Khi^T + Qhi Klo^T + Qlo Khi^T          (the lo.lo term is below 2^-22 of the result and dropped)
+//     O^T = Vhi^T Phi^T + Vhi^T Plo^T + Vlo^T Phi^T
+// f16 x f16 products are exact in the MFMA's fp32 accumulator, so what remains is fp32 summation noise: the forward of
+// timing.py:58 (`model(mel, tokens)` with fp32 parameters under disable_sdpa(): qk = (q*s)@(k*s)^T; softmax(qk.float()); @v) at
+// fp32 accuracy on the f16 matrix pipe. Selected by AttnArgs.split (wca_set_precision(e, WCA_PRECISION_SPLIT)); used for the
+// encoder self-attention, the decoder's causal self-attention and the cross-attention with CAPTURE of the pre-softmax logits
+// (timing.py:50-55) -- the captured values are the three-pass fp32 sums times scale.
+//
+// Structure (deliberately the simple one; this mode trades speed for the reference's precision): 256-thread workgroup = 4 waves
+// x 32 query rows, two workgroups per CU; 64-key tiles of K hi | K lo | V hi | V lo (4 x 8 KiB) in a ring of two LDS slots
+// filled by LDS-DMA one tile ahead; one barrier per tile (at the top: tile kt has landed for every wave, and every wave is done
+// with the slot that tile kt + 1 is then requested into). Scores transposed (S^T = K Q^T) so that a query row is a lane column;
+// textbook online softmax in fp32 on the RAW scores (no deferred maximum, no pre-scaled Q: nothing is rounded to f16 before
+// the exponential); P is split like every other operand.
+#include "kernels.h"
+#include "wca_common.h"
+
+namespace wca {
+
+namespace {
+
+constexpr int KT = 64;
+constexpr int TILE = 64 * 64;  // f16 elements of one 64-key x 64-dim tile
+constexpr float LOG2E = 1.4426950408889634f;
+
+__device__ __forceinline__ float xor16_maxf(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor32_maxf(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_sumf(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_sumf(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ half4 tr_read4s(const half_t* p) {
+  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WCA_LDS s16x4*)(p));
+  return __builtin_bit_cast(half4, r);
+}
+
+template <bool CAUSAL, bool CAPTURE>
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);  // [slot][K hi | K lo | V hi | V lo]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_qt = (a.nq + 127) / 128;
+  const int lid = xcd_remap(blockIdx.x, n_qt * a.H * a.B);
+  const int bh = lid / n_qt;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q_blk = (lid - bh * n_qt) * 128;
+  const int q_wave = q_blk + wave * 32;
+
+  // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = fr][dd = ks*32 + 8*fg + j], hi and lo halves
+  half8 qh[2][2], ql[2][2];
+  int qrow[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    qrow[sub] = q_wave + sub * 16 + fr;
+    const int qc = qrow[sub] < a.nq ? qrow[sub] : a.nq - 1;
+    const half_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + h * 64 + fg * 8;
+    qh[sub][0] = *reinterpret_cast<const half8*>(qp);
+    qh[sub][1] = *reinterpret_cast<const half8*>(qp + 32);
+    ql[sub][0] = *reinterpret_cast<const half8*>(qp + a.q_lo);
+    ql[sub][1] = *reinterpret_cast<const half8*>(qp + a.q_lo + 32);
+  }
+  const float c_log2 = a.scale * LOG2E;
+
+  int nk_eff = a.nk;
+  if (CAUSAL) {
+    const int qhi = q_blk + 128;
+    nk_eff = qhi < a.nk ? qhi : a.nk;
+  }
+  const int nkt = (nk_eff + KT - 1) / KT;
+
+  const half_t* Kb = a.K + (long)b * a.k_bs + h * 64;
+  const half_t* Vb = a.V + (long)b * a.v_bs + h * 64;
+
+  // a wave fills rows (wave*2 + i)*8 .. +7 of each of the four tiles: lane -> row + (lane >> 3), 16-byte chunk lane & 7 of the LDS
+  // row, which holds global chunk (lane & 7) ^ swizzle(row) (K: swz128, conflict-free ds_read_b128; V: row & 6, transposed reads)
+  auto stage = [&](int buf, int kt) {
+    half_t* Kh = lds + buf * (4 * TILE);
+    half_t* Kl = Kh + TILE;
+    half_t* Vh = Kl + TILE;
+    half_t* Vl = Vh + TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (wave * 2 + i) * 8;
+      const int r = rbase + (lane >> 3);
+      int key = kt * KT + r;
+      key = key < a.nk ? key : a.nk - 1;  // rows past nk: a duplicate of the last key, masked to -inf below
+      const int ck = (lane & 7) ^ swz128(r);
+      const int cv = (lane & 7) ^ (r & 6);
+      const half_t* kp = Kb + (long)key * a.k_rs + ck * 8;
+      const half_t* vp = Vb + (long)key * a.v_rs + cv * 8;
+      glds16(kp, Kh + rbase * 64);
+      glds16(kp + a.k_lo, Kl + rbase * 64);
+      glds16(vp, Vh + rbase * 64);
+      glds16(vp + a.v_lo, Vl + rbase * 64);
+    }
+  };
+
+  f32x4 ot[2][4];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-INFINITY, -INFINITY};  // running row maximum of the RAW scores
+  float l_part[2] = {0.f, 0.f};             // this lane's share of the row sum (its 16 keys per tile), reduced at the end
+
+  stage(0, 0);
+  for (int kt = 0; kt < nkt; ++kt) {
+    wait_vm0();                      // this wave's requests of tile kt (the only ones in flight) have landed
+    __builtin_amdgcn_s_barrier();    // ... and everyone's; every wave has also finished reading the other slot (tile kt - 1)
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+    const half_t* Kh = lds + (kt & 1) * (4 * TILE);
+    const half_t* Kl = Kh + TILE;
+    const half_t* Vh = Kl + TILE;
+    const half_t* Vl = Vh + TILE;
+
+    // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r], three passes per 32-deep k step
+    f32x4 st[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 kh[4], kl[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = t * 16 + fr;
+        const int off = r * 64 + (((ks * 4 + fg) ^ swz128(r)) << 3);
+        kh[t] = *reinterpret_cast<const half8*>(Kh + off);
+        kl[t] = *reinterpret_cast<const half8*>(Kl + off);
+      }
+      // the small terms first, the hi.hi product last
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t], qh[s][ks], st[s][t], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], ql[s][ks], st[s][t], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], qh[s][ks], st[s][t], 0, 0, 0);
+    }
+
+    if (CAPTURE) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        if (qrow[s] < a.nq) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int key4 = kt * KT + t * 16 + 4 * fg;
+            if (key4 < a.cap_cols) {
+              float* cp = a.cap + (long)b * a.cap_bs + (long)h * a.cap_hs + (long)qrow[s] * a.cap_ld + key4;
+              *reinterpret_cast<f32x4*>(cp) = st[s][t] * a.scale;
+            }
+          }
+        }
+      }
+    }
+    const bool tail_tile = (kt * KT + KT > a.nk);
+    const bool diag_tile = CAUSAL && (kt * KT + KT - 1 > q_wave);
+    if (tail_tile || diag_tile) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = kt * KT + t * 16 + 4 * fg + r;
+            bool dead = key >= a.nk;
+            if (CAUSAL) dead = dead || (key > qrow[s]);
+            st[s][t][r] = dead ? -INFINITY : st[s][t][r];
+          }
+    }
+    float mx[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      float m = st[s][0][0];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m = fmaxf(m, st[s][t][r]);
+      mx[s] = xor32_maxf(xor16_maxf(m));
+    }
+    if (__any((mx[0] > m_run[0]) || (mx[1] > m_run[1]))) {  // wave-uniform: some row's running maximum grows
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const float m_new = fmaxf(m_run[s], mx[s]);
+        const float alpha = (m_run[s] == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run[s] - m_new) * c_log2);  // m_new finite here
+        l_part[s] *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
+        m_run[s] = m_new;
+      }
+    }
+    // p = exp((s - m) * scale) as exp2(((s - m) * c)): the difference first (exact for nearby values), one rounding in the product
+    half8 ph[2][2], pl[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float mref = (m_run[s] == -INFINITY) ? 0.f : m_run[s];  // a row that has only seen masked keys: exp2(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f((st[s][t][r] - mref) * c_log2);
+          st[s][t][r] = p;
+          psum += p;
+        }
+      l_part[s] += psum;
+      // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        half8 fh, fl;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p0 = st[s][2 * k2][r], p1 = st[s][2 * k2 + 1][r];
+          fh[r] = (half_t)p0;
+          fl[r] = (half_t)(p0 - (float)fh[r]);
+          fh[4 + r] = (half_t)p1;
+          fl[4 + r] = (half_t)(p1 - (float)fh[4 + r]);
+        }
+        ph[s][k2] = fh;
+        pl[s][k2] = fl;
+      }
+    }
+
+    // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr], k order matching the P fragments:
+    // j<4 -> key (2*k2)*16 + 4*fg + j, j>=4 -> key (2*k2+1)*16 + 4*fg + (j-4).
+    {
+      const int qd = fr >> 2, pd = fr & 3;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int d = dt * 16 + 4 * pd;
+        const int c = d >> 3, w = d & 7;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const int key0 = (2 * k2) * 16 + 4 * fg + qd;
+          const int key1 = key0 + 16;
+          const int o0 = key0 * 64 + ((c ^ (key0 & 6)) << 3) + w, o1 = key1 * 64 + ((c ^ (key1 & 6)) << 3) + w;
+          const half4 h0 = tr_read4s(Vh + o0), h1 = tr_read4s(Vh + o1);
+          const half4 l0 = tr_read4s(Vl + o0), l1 = tr_read4s(Vl + o1);
+          const half8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const half8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[s][k2], ot[s][dt], 0, 0, 0);
+            ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl[s][k2], ot[s][dt], 0, 0, 0);
+            ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[s][k2], ot[s][dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: ot[s][dt][r] = O[q = fr][d = dt*16 + 4*fg + r]; a row's sum is spread over its four lane groups
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float l = xor32_sumf(xor16_sumf(l_part[s]));
+    if (qrow[s] >= a.nq) continue;
+    const float inv = 1.0f / l;
+    half_t* op = a.O + (long)b * a.o_bs + (long)qrow[s] * a.o_rs + h * 64 + 4 * fg;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      half4 oh, ol;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float o = ot[s][dt][r] * inv;
+        oh[r] = (half_t)o;
+        ol[r] = (half_t)(o - (float)oh[r]);
+      }
+      *reinterpret_cast<half4*>(op + dt * 16) = oh;
+      *reinterpret_cast<half4*>(op + a.o_lo + dt * 16) = ol;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
+  if (a.nq <= 0 || a.B <= 0) return hipSuccess;
+  if (a.nk <= 0) return hipErrorInvalidValue;
+  if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;
+  if ((a.q_lo % 8) || (a.k_lo % 8) || (a.v_lo % 8) || (a.o_lo % 4) || a.q_lo <= 0 || a.k_lo <= 0 || a.v_lo <= 0 || a.o_lo <= 0) return hipErrorInvalidValue;
+  if (a.cap != nullptr && ((a.cap_ld % 4) != 0 || a.cap_ld < ((a.cap_cols + 3) & ~3))) return hipErrorInvalidValue;
+  const bool cap = a.cap != nullptr && a.cap_cols > 0;
+  dim3 grid(((a.nq + 127) / 128) * a.H * a.B), block(256);
+  const size_t shmem = 2 * 4 * TILE * sizeof(half_t);  // 64 KiB: two slots of K hi | K lo | V hi | V lo
+#define WCA_LAUNCH_AS(C, P)                                                                                                  \
+  do {                                                                                                                       \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<C, P>),                               \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                             \
+    if (e != hipSuccess) return e;                                                                                           \
+    hipLaunchKernelGGL((attn_split_kernel<C, P>), grid, block, shmem, s, a);                                                 \
+  } while (0)
+  if (a.causal) {
+    if (cap) WCA_LAUNCH_AS(true, true); else WCA_LAUNCH_AS(true, false);
+  } else {
+    if (cap) WCA_LAUNCH_AS(false, true); else WCA_LAUNCH_AS(false, false);
+  }
+#undef WCA_LAUNCH_AS
+  return hipGetLastError();
+}
+
+}  // namespace wca

@@ -10,10 +10,11 @@ namespace {
 
 // One wave per row, the whole row in registers (two passes over registers, one over HBM).
 // NV = 16-byte vectors per lane: d = 256 * NV (d = 256 .. 1280); d = 128 / 384 use the 8-byte variant.
-template <int NV>
+// SPLIT: the output row (ld_out elements apart) carries hi = f16(y) at [0, d) and lo = f16(y - hi) at [lo_off, lo_off + d)
+template <int NV, bool SPLIT = false>
 __global__ __launch_bounds__(256) void layernorm_f16_v4_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, half_t* __restrict__ out,
-                                                               int rows, float eps) {
+                                                               int rows, float eps, int ld_out, long lo_off) {
   constexpr int d = 256 * NV;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -39,21 +40,27 @@ __global__ __launch_bounds__(256) void layernorm_f16_v4_kernel(const float* __re
   const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + eps);
   const f32x4* g4 = reinterpret_cast<const f32x4*>(gamma);
   const f32x4* b4 = reinterpret_cast<const f32x4*>(beta);
-  half4* o4 = reinterpret_cast<half4*>(out + (long)row * d);
+  half4* o4 = reinterpret_cast<half4*>(out + (long)row * ld_out);
+  half4* l4 = reinterpret_cast<half4*>(out + (long)row * ld_out + lo_off);
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const f32x4 g = g4[i * 64 + lane], bb = b4[i * 64 + lane];
-    half4 o;
+    half4 o, ol;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = (half_t)((v[i][j] - mean) * rstd * g[j] + bb[j]);
+    for (int j = 0; j < 4; ++j) {
+      const float y = (v[i][j] - mean) * rstd * g[j] + bb[j];
+      o[j] = (half_t)y;
+      if (SPLIT) ol[j] = (half_t)(y - (float)o[j]);
+    }
     o4[i * 64 + lane] = o;
+    if (SPLIT) l4[i * 64 + lane] = ol;
   }
 }
 
-template <int NV2>  // d = 128 * NV2
+template <int NV2, bool SPLIT = false>  // d = 128 * NV2
 __global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, half_t* __restrict__ out,
-                                                               int rows, float eps) {
+                                                               int rows, float eps, int ld_out, long lo_off) {
   constexpr int d = 128 * NV2;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -76,14 +83,22 @@ __global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __re
   const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + eps);
   const f32x2* g2 = reinterpret_cast<const f32x2*>(gamma);
   const f32x2* b2 = reinterpret_cast<const f32x2*>(beta);
-  half2_* o2 = reinterpret_cast<half2_*>(out + (long)row * d);
+  half2_* o2 = reinterpret_cast<half2_*>(out + (long)row * ld_out);
+  half2_* l2 = reinterpret_cast<half2_*>(out + (long)row * ld_out + lo_off);
 #pragma unroll
   for (int i = 0; i < NV2; ++i) {
     const f32x2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
+    const float y0 = (v[i][0] - mean) * rstd * g[0] + bb[0], y1 = (v[i][1] - mean) * rstd * g[1] + bb[1];
     half2_ o;
-    o[0] = (half_t)((v[i][0] - mean) * rstd * g[0] + bb[0]);
-    o[1] = (half_t)((v[i][1] - mean) * rstd * g[1] + bb[1]);
+    o[0] = (half_t)y0;
+    o[1] = (half_t)y1;
     o2[i * 64 + lane] = o;
+    if (SPLIT) {
+      half2_ ol;
+      ol[0] = (half_t)(y0 - (float)o[0]);
+      ol[1] = (half_t)(y1 - (float)o[1]);
+      l2[i * 64 + lane] = ol;
+    }
   }
 }
 
@@ -121,19 +136,27 @@ __global__ void f32_to_f16_kernel(const float* __restrict__ in, half_t* __restri
 }  // namespace
 
 hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out, int rows, int d,
-                                float eps, hipStream_t s) {
+                                float eps, hipStream_t s, int ld_out, long lo_off) {
   if (rows <= 0) return hipSuccess;
+  if (ld_out <= 0) ld_out = d;
+  if ((ld_out & 3) || (lo_off & 3) || lo_off < 0) return hipErrorInvalidValue;
   dim3 grid((rows + 3) / 4), block(256);
+#define WCA_LN(KERN, NV)                                                                                                           \
+  do {                                                                                                                             \
+    if (lo_off) hipLaunchKernelGGL((KERN<NV, true>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off);           \
+    else hipLaunchKernelGGL((KERN<NV, false>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off);                 \
+  } while (0)
   switch (d) {
-    case 128: hipLaunchKernelGGL((layernorm_f16_v2_kernel<1>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 256: hipLaunchKernelGGL((layernorm_f16_v4_kernel<1>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 384: hipLaunchKernelGGL((layernorm_f16_v2_kernel<3>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 512: hipLaunchKernelGGL((layernorm_f16_v4_kernel<2>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 768: hipLaunchKernelGGL((layernorm_f16_v4_kernel<3>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 1024: hipLaunchKernelGGL((layernorm_f16_v4_kernel<4>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
-    case 1280: hipLaunchKernelGGL((layernorm_f16_v4_kernel<5>), grid, block, 0, s, x, gamma, beta, out, rows, eps); break;
+    case 128: WCA_LN(layernorm_f16_v2_kernel, 1); break;
+    case 256: WCA_LN(layernorm_f16_v4_kernel, 1); break;
+    case 384: WCA_LN(layernorm_f16_v2_kernel, 3); break;
+    case 512: WCA_LN(layernorm_f16_v4_kernel, 2); break;
+    case 768: WCA_LN(layernorm_f16_v4_kernel, 3); break;
+    case 1024: WCA_LN(layernorm_f16_v4_kernel, 4); break;
+    case 1280: WCA_LN(layernorm_f16_v4_kernel, 5); break;
     default: return hipErrorInvalidValue;
   }
+#undef WCA_LN
   return hipGetLastError();
 }
 

@@ -201,6 +201,18 @@ struct wca_engine {
   // start/stop pairs around each kernel of every encoder layer (profiling only): site = WCA_SITE_* of include/wca.h
   hipEvent_t kev[WCA_N_SITES][33][2] = {};   // slot 32: ln_post of a 32-layer encoder (site LN1, slot n_layer)
   bool kev_set[WCA_N_SITES][33] = {};   // which (site, layer) pairs the last encoder run recorded
+  // ---- reference-precision ("split") mode, wca_set_precision: every f16 GEMM / attention operand x travels as the pair
+  // hi = f16(x), lo = f16(x - hi) in ONE row [hi(K) | lo(K)], and every weight matrix as [W | W] ([N][2K], built once on the
+  // device from the f16 weights, which are exact): A.W^T = [A_hi | A_lo].[W | W]^T is then a K-doubled call of the SAME GEMM
+  // kernels with f16 x f16 products exact in the fp32 accumulator. Activation operand buffers are twice as wide.
+  bool split = false;
+  char* wslab2 = nullptr;    // the K-doubled weight copies (allocated while split is on)
+  bool sw_dirty = true;      // a weight was (re)loaded since the copies were built
+  struct SplitW {
+    half_t *conv1_w = nullptr, *conv2_w = nullptr, *kv_w = nullptr, *tok_emb = nullptr;
+    int k1pad = 0;           // padded K of the split conv1 GEMM: windows of 3 frames x [hi(C) | lo(C)]
+    std::vector<LayerW> enc, dec;  // only the half_t* members are used
+  } sw;
   bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
@@ -290,25 +302,26 @@ size_t layout_weights(wca_engine* e, char* base) {
 size_t layout_arena(wca_engine* e, char* base) {
   const wca_model_dims& D = e->dims;
   const size_t B = e->max_batch, d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
+  const size_t om = e->split ? 2 : 1;  // f16 operand buffers hold [hi | lo] rows in split mode
   char* cur = base;
   e->mel_scratch = carve<float>(cur, B * D.n_mels * N_FRAMES);
   e->gmax = carve<unsigned>(cur, B);
   e->mel_f32 = carve<float>(cur, B * D.n_mels * N_FRAMES);
-  e->mel_tm = carve<half_t>(cur, B * (N_FRAMES + 2) * D.n_mels + 4096);
-  e->h1pad = carve<half_t>(cur, B * (N_FRAMES + 2) * d + 4096);
+  e->mel_tm = carve<half_t>(cur, om * B * (N_FRAMES + 2) * D.n_mels + 4096);
+  e->h1pad = carve<half_t>(cur, om * B * (N_FRAMES + 2) * d + 4096);
   e->x = carve<float>(cur, B * N_CTX * d);
-  e->xn = carve<half_t>(cur, B * N_CTX * d);
-  e->qkv = carve<half_t>(cur, B * N_CTX * 3 * d);
-  e->att = carve<half_t>(cur, B * N_CTX * d);
-  e->hid = carve<half_t>(cur, B * N_CTX * 4 * d);
-  e->kv = carve<half_t>(cur, B * N_CTX * L * 2 * dt);
-  e->kv_alt = carve<half_t>(cur, B * N_CTX * L * 2 * dt);
+  e->xn = carve<half_t>(cur, om * B * N_CTX * d);
+  e->qkv = carve<half_t>(cur, om * B * N_CTX * 3 * d);
+  e->att = carve<half_t>(cur, om * B * N_CTX * d);
+  e->hid = carve<half_t>(cur, om * B * N_CTX * 4 * d);
+  e->kv = carve<half_t>(cur, om * B * N_CTX * L * 2 * dt);
+  e->kv_alt = carve<half_t>(cur, om * B * N_CTX * L * 2 * dt);
   e->xd = carve<float>(cur, B * MAX_TOK * dt);
-  e->xdn = carve<half_t>(cur, B * MAX_TOK * dt);
-  e->qkv_d = carve<half_t>(cur, B * MAX_TOK * 3 * dt);
-  e->att_d = carve<half_t>(cur, B * MAX_TOK * dt);
-  e->q_d = carve<half_t>(cur, B * MAX_TOK * dt);
-  e->hid_d = carve<half_t>(cur, B * MAX_TOK * 4 * dt);
+  e->xdn = carve<half_t>(cur, om * B * MAX_TOK * dt);
+  e->qkv_d = carve<half_t>(cur, om * B * MAX_TOK * 3 * dt);
+  e->att_d = carve<half_t>(cur, om * B * MAX_TOK * dt);
+  e->q_d = carve<half_t>(cur, om * B * MAX_TOK * dt);
+  e->hid_d = carve<half_t>(cur, om * B * MAX_TOK * 4 * dt);
   e->meta_dev = carve<int>(cur, (size_t)META_SLOTS * 4 * B);
   e->err_dev = carve<int>(cur, 64);
   {
@@ -332,11 +345,99 @@ size_t layout_arena(wca_engine* e, char* base) {
   return (size_t)(cur - base) + 4096;
 }
 
+// ---- split mode: the K-doubled weight copies (two passes like layout_weights: size, then carve)
+size_t layout_split_weights(wca_engine* e, char* base) {
+  const wca_model_dims& D = e->dims;
+  const size_t d = D.n_audio_state, dt = D.n_text_state;
+  char* cur = base;
+  e->sw.k1pad = (int)align_up((size_t)6 * D.n_mels, 64);
+  e->sw.conv1_w = carve<half_t>(cur, d * e->sw.k1pad);
+  e->sw.conv2_w = carve<half_t>(cur, d * 6 * d);
+  e->sw.enc.assign(D.n_audio_layer, LayerW{});
+  for (auto& l : e->sw.enc) {
+    l.qkv_w = carve<half_t>(cur, 3 * d * 2 * d);
+    l.out_w = carve<half_t>(cur, d * 2 * d);
+    l.fc1_w = carve<half_t>(cur, 4 * d * 2 * d);
+    l.fc2_w = carve<half_t>(cur, d * 8 * d);
+  }
+  e->sw.tok_emb = carve<half_t>(cur, (size_t)D.n_vocab * 2 * dt);
+  e->sw.kv_w = carve<half_t>(cur, (size_t)D.n_text_layer * 2 * dt * 2 * d);
+  e->sw.dec.assign(D.n_text_layer, LayerW{});
+  for (auto& l : e->sw.dec) {
+    l.qkv_w = carve<half_t>(cur, 3 * dt * 2 * dt);
+    l.out_w = carve<half_t>(cur, dt * 2 * dt);
+    l.cq_w = carve<half_t>(cur, dt * 2 * dt);
+    l.co_w = carve<half_t>(cur, dt * 2 * dt);
+    l.fc1_w = carve<half_t>(cur, 4 * dt * 2 * dt);
+    l.fc2_w = carve<half_t>(cur, dt * 8 * dt);
+  }
+  return (size_t)(cur - base) + 4096;
+}
+
+// dst[n][(j / grp) * 2 * grp + (j % grp) + {0, grp}] = src[n][j] for j < K: every group of `grp` source columns is written twice,
+// side by side. grp = K: [W | W] (a Linear weight against [hi(K) | lo(K)] activation rows); grp = channels of a conv input: the
+// taps of the time-major conv GEMM against frames stored as [hi(C) | lo(C)]. Columns of dst past 2 K stay zero.
+__global__ void dup_cols_kernel(const half_t* __restrict__ src, int ld_src, half_t* __restrict__ dst, int ld_dst, long N, int K, int grp) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * K) return;
+  const long n = i / K;
+  const int j = (int)(i - n * K);
+  const half_t v = src[n * ld_src + j];
+  const int g = j / grp, c = j - g * grp;
+  half_t* o = dst + n * ld_dst + (long)g * 2 * grp + c;
+  o[0] = v;
+  o[grp] = v;
+}
+
+int dup_cols(hipStream_t s, const half_t* src, int ld_src, half_t* dst, int ld_dst, long N, int K, int grp) {
+  const long tot = N * K;
+  hipLaunchKernelGGL(dup_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, N, K, grp);
+  HIPCHK(hipGetLastError());
+  return WCA_OK;
+}
+
+// (re)build the K-doubled copies from the resident f16 weights when a weight changed since the last build
+int ensure_split_weights(wca_engine* e) {
+  if (!e->split || !e->sw_dirty) return WCA_OK;
+  const wca_model_dims& D = e->dims;
+  const int d = D.n_audio_state, dt = D.n_text_state, C = D.n_mels;
+  hipStream_t s = e->stream;
+  WCA_TRY(dup_cols(s, e->conv1_w, e->k1pad, e->sw.conv1_w, e->sw.k1pad, d, 3 * C, C));
+  WCA_TRY(dup_cols(s, e->conv2_w, 3 * d, e->sw.conv2_w, 6 * d, d, 3 * d, d));
+  for (int li = 0; li < D.n_audio_layer; ++li) {
+    const LayerW& l = e->enc[li];
+    const LayerW& w = e->sw.enc[li];
+    WCA_TRY(dup_cols(s, l.qkv_w, d, w.qkv_w, 2 * d, 3 * d, d, d));
+    WCA_TRY(dup_cols(s, l.out_w, d, w.out_w, 2 * d, d, d, d));
+    WCA_TRY(dup_cols(s, l.fc1_w, d, w.fc1_w, 2 * d, 4 * d, d, d));
+    WCA_TRY(dup_cols(s, l.fc2_w, 4 * d, w.fc2_w, 8 * d, d, 4 * d, 4 * d));
+  }
+  WCA_TRY(dup_cols(s, e->tok_emb, dt, e->sw.tok_emb, 2 * dt, D.n_vocab, dt, dt));
+  WCA_TRY(dup_cols(s, e->kv_w, d, e->sw.kv_w, 2 * d, (long)D.n_text_layer * 2 * dt, d, d));
+  for (int li = 0; li < D.n_text_layer; ++li) {
+    const LayerW& l = e->dec[li];
+    const LayerW& w = e->sw.dec[li];
+    WCA_TRY(dup_cols(s, l.qkv_w, dt, w.qkv_w, 2 * dt, 3 * dt, dt, dt));
+    WCA_TRY(dup_cols(s, l.out_w, dt, w.out_w, 2 * dt, dt, dt, dt));
+    WCA_TRY(dup_cols(s, l.cq_w, dt, w.cq_w, 2 * dt, dt, dt, dt));
+    WCA_TRY(dup_cols(s, l.co_w, dt, w.co_w, 2 * dt, dt, dt, dt));
+    WCA_TRY(dup_cols(s, l.fc1_w, dt, w.fc1_w, 2 * dt, 4 * dt, dt, dt));
+    WCA_TRY(dup_cols(s, l.fc2_w, 4 * dt, w.fc2_w, 8 * dt, dt, 4 * dt, 4 * dt));
+  }
+  // the copies are read by kernels on stream2 / stream3 too: make them visible before anything else is enqueued
+  HIPCHK(hipStreamSynchronize(s));
+  e->sw_dirty = false;
+  return WCA_OK;
+}
+
+// c_lo > 0 (split mode, f16 output): the value is stored as the pair hi at C, lo at C + c_lo (out_mode 4)
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
-                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0) {
+                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0) {
   GemmArgs g{};
   g.sk_part = sk_ws;
   g.sk_bytes = sk_bytes;
+  g.c_lo = c_lo;
+  if (c_lo > 0 && out_mode == 0) out_mode = 4;
   g.A = A;
   g.lda = lda;
   g.W = W;
@@ -420,7 +521,8 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     }
   };
   ev(ev_gemm_site, ev_gemm_li, 0);
-  if (allow_fused && gemm_ln_supported(M, N, K, e->n_cu)) {
+  const int om = e->split ? 2 : 1;  // split mode: xn rows are [hi(N) | lo(N)] (K is already the doubled depth); no fused form
+  if (allow_fused && !e->split && gemm_ln_supported(M, N, K, e->n_cu)) {
     GemmArgs g{};
     g.A = A;
     g.lda = lda;
@@ -449,7 +551,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
   HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes));
   ev(ev_gemm_site, ev_gemm_li, 1);
   ev(ev_ln_site, ev_ln_li, 0);
-  HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s));
+  HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s, om * N, e->split ? N : 0));
   ev(ev_ln_site, ev_ln_li, 1);
   return WCA_OK;
 }
@@ -545,39 +647,44 @@ int join_phase2(wca_engine* e) {
 }
 
 // ---- encoder: mel_tm (f16 time-major) -> xn = ln_post(x) (f16) and optionally x (f32)
+// Split mode (e->split): the same launches on [hi | lo] operand rows (row width om * width, lo half `width` elements after the
+// hi half) against the K-doubled weight copies; f16 outputs are stored as pairs (out_mode 4), the fp32 residual stream is as before.
 int run_encoder(wca_engine* e, int B) {
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, H = D.n_audio_head;
+  const bool sp = e->split;
+  const int om = sp ? 2 : 1;
   hipStream_t s = e->stream;
   {
     GemmArgs g{};
     g.A = e->mel_tm;
-    g.lda = D.n_mels;
+    g.lda = om * D.n_mels;
     g.a_rows_per_batch = N_FRAMES;
-    g.a_batch_stride = (long)(N_FRAMES + 2) * D.n_mels;
-    g.W = e->conv1_w;
-    g.ldw = e->k1pad;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * om * D.n_mels;
+    g.W = sp ? e->sw.conv1_w : e->conv1_w;
+    g.ldw = sp ? e->sw.k1pad : e->k1pad;
     g.bias = e->conv1_b;
-    g.C = e->h1pad + d;  // output frame t lands in padded row t + 1
-    g.ldc = d;
+    g.C = e->h1pad + om * d;  // output frame t lands in padded row t + 1
+    g.ldc = om * d;
     g.c_rows_per_batch = N_FRAMES;
-    g.c_batch_stride = (long)(N_FRAMES + 2) * d;
+    g.c_batch_stride = (long)(N_FRAMES + 2) * om * d;
+    g.c_lo = sp ? d : 0;
     g.M = B * N_FRAMES;
     g.N = d;
-    g.K = e->k1pad;
+    g.K = g.ldw;
     g.gelu = 1;
-    g.out_mode = 0;
+    g.out_mode = sp ? 4 : 0;
     g.site = 3;
     HIPCHK(launch_gemm(g, s));
   }
   {
     GemmArgs g{};
     g.A = e->h1pad;
-    g.lda = 2 * d;  // stride 2
+    g.lda = 2 * om * d;  // stride 2
     g.a_rows_per_batch = N_CTX;
-    g.a_batch_stride = (long)(N_FRAMES + 2) * d;
-    g.W = e->conv2_w;
-    g.ldw = 3 * d;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * om * d;
+    g.W = sp ? e->sw.conv2_w : e->conv2_w;
+    g.ldw = 3 * om * d;
     g.bias = e->conv2_b;
     g.C = e->x;
     g.ldc = d;
@@ -585,7 +692,7 @@ int run_encoder(wca_engine* e, int B) {
     g.pos_period = N_CTX;
     g.M = B * N_CTX;
     g.N = d;
-    g.K = 3 * d;
+    g.K = 3 * om * d;
     g.gelu = 1;
     g.out_mode = 1;
     g.site = 3;
@@ -602,24 +709,28 @@ int run_encoder(wca_engine* e, int B) {
   };
   // LayerNorms ride in the epilogue of the GEMM that produces their input (gemm_residual_ln): mlp_ln in the attention
   // out-projection, the NEXT layer's attn_ln (ln_post after the last layer) in fc2; only layer 0's attn_ln is a launch
-  const bool fuse_ln = e->fuse_ln;
+  const bool fuse_ln = e->fuse_ln && !sp;
   mark(WCA_SITE_LN1, 0, 0);
-  HIPCHK(launch_layernorm_f16(e->x, e->enc[0].ln1_g, e->enc[0].ln1_b, e->xn, M, d, 1e-5f, s));
+  HIPCHK(launch_layernorm_f16(e->x, e->enc[0].ln1_g, e->enc[0].ln1_b, e->xn, M, d, 1e-5f, s, om * d, sp ? d : 0));
   mark(WCA_SITE_LN1, 0, 1);
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
+    const LayerW& w = sp ? e->sw.enc[li] : l;  // the f16 matrices ([N][K], or [N][2K] = [W | W] in split mode)
     mark(WCA_SITE_QKV, li, 0);
-    HIPCHK(gemm(s, e->xn, d, l.qkv_w, d, l.qkv_b, e->qkv, 3 * d, M, 3 * d, d, 0, 0, 1));
+    HIPCHK(gemm(s, e->xn, om * d, w.qkv_w, om * d, l.qkv_b, e->qkv, om * 3 * d, M, 3 * d, om * d, 0, 0, 1, nullptr, 0, sp ? 3 * d : 0));
     mark(WCA_SITE_QKV, li, 1);
     AttnArgs a{};
     a.Q = e->qkv;
     a.K = e->qkv + d;
     a.V = e->qkv + 2 * d;
-    a.q_bs = a.k_bs = a.v_bs = (long)N_CTX * 3 * d;
-    a.q_rs = a.k_rs = a.v_rs = 3 * d;
+    a.q_bs = a.k_bs = a.v_bs = (long)N_CTX * om * 3 * d;
+    a.q_rs = a.k_rs = a.v_rs = om * 3 * d;
     a.O = e->att;
-    a.o_bs = (long)N_CTX * d;
-    a.o_rs = d;
+    a.o_bs = (long)N_CTX * om * d;
+    a.o_rs = om * d;
+    a.split = sp ? 1 : 0;
+    a.q_lo = a.k_lo = a.v_lo = 3 * d;
+    a.o_lo = d;
     a.nq = N_CTX;
     a.nk = N_CTX;
     a.H = H;
@@ -631,14 +742,14 @@ int run_encoder(wca_engine* e, int B) {
     mark(WCA_SITE_ATTN, li, 1);
     // sites OUT / FC2 = the GEMM alone (or the fused GEMM + LayerNorm kernel); the LayerNorm launches: mlp_ln = LN2[li], the next
     // layer's attn_ln / ln_post = LN1[li + 1]
-    if (int rc = gemm_residual_ln(e, s, e->att, d, l.out_w, d, l.out_b, e->x, M, d, d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln, WCA_SITE_OUT, li,
-                                  WCA_SITE_LN2, li))
+    if (int rc = gemm_residual_ln(e, s, e->att, om * d, w.out_w, om * d, l.out_b, e->x, M, d, om * d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln, WCA_SITE_OUT,
+                                  li, WCA_SITE_LN2, li))
       return rc;
     mark(WCA_SITE_FC1, li, 0);
-    HIPCHK(gemm(s, e->xn, d, l.fc1_w, d, l.fc1_b, e->hid, 4 * d, M, 4 * d, d, 1, 0, 1));
+    HIPCHK(gemm(s, e->xn, om * d, w.fc1_w, om * d, l.fc1_b, e->hid, om * 4 * d, M, 4 * d, om * d, 1, 0, 1, nullptr, 0, sp ? 4 * d : 0));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
-    if (int rc = gemm_residual_ln(e, s, e->hid, 4 * d, l.fc2_w, 4 * d, l.fc2_b, e->x, M, d, 4 * d, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
+    if (int rc = gemm_residual_ln(e, s, e->hid, om * 4 * d, w.fc2_w, om * 4 * d, l.fc2_b, e->x, M, d, om * 4 * d, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
                                   last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, 4, fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1))
       return rc;
   }
@@ -653,7 +764,103 @@ int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
   const int n_cols = L * 2 * dt - (skip_last_v ? dt : 0);
-  HIPCHK(gemm(e->stream, e->xn, d, e->kv_w, d, e->kv_b, kvbuf, L * 2 * dt, B * N_CTX, n_cols, d, 0, 0, 3));
+  const bool sp = e->split;
+  const int om = sp ? 2 : 1;  // split: rows [hi(L*2*dt) | lo(L*2*dt)]
+  HIPCHK(gemm(e->stream, e->xn, om * d, sp ? e->sw.kv_w : e->kv_w, om * d, e->kv_b, kvbuf, om * L * 2 * dt, B * N_CTX, n_cols, om * d, 0, 0, 3, nullptr, 0,
+              sp ? (long)L * 2 * dt : 0));
+  return WCA_OK;
+}
+
+// The teacher-forced decoder in split mode: separate LayerNorm launches writing [hi | lo] rows, the tile GEMMs on the K-doubled
+// weight copies (the few-row kernel of gemm_rows.hip has no pair output), attn_split_kernel for both attentions. The captured
+// logits are the three-pass fp32 sums.
+int run_decoder_split(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out, hipStream_t s,
+                      const half_t* kvbuf) {
+  const wca_model_dims& D = e->dims;
+  const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
+  const int M = B * n;
+  const float scale = 1.0f / std::sqrt((float)(dt / H));
+  const int kv_ld = 2 * L * 2 * dt;
+  const long kv_lo = (long)L * 2 * dt;
+  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
+  auto ln = [&](const float* g, const float* b) -> int {
+    HIPCHK(launch_layernorm_f16(e->xd, g, b, e->xdn, M, dt, 1e-5f, s, 2 * dt, dt));
+    return WCA_OK;
+  };
+  // C = A W2^T (+ bias ...): A rows [hi | lo] of K2 = 2 K elements, W2 = [W | W]; c_lo > 0: f16 pair output
+  auto mm = [&](const half_t* A, int lda, const half_t* W2, const float* bias, void* C, int ldc, int N, int K2, int gelu, int out_mode, long c_lo,
+                int site) -> int {
+    HIPCHK(gemm(s, A, lda, W2, K2, bias, C, ldc, M, N, K2, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo));
+    return WCA_OK;
+  };
+  for (int li = 0; li < L; ++li) {
+    const LayerW& l = e->dec[li];
+    const LayerW& w = e->sw.dec[li];
+    WCA_TRY(ln(l.ln1_g, l.ln1_b));
+    WCA_TRY(mm(e->xdn, 2 * dt, w.qkv_w, l.qkv_b, e->qkv_d, 6 * dt, 3 * dt, 2 * dt, 0, 0, 3 * dt, 2));
+    {
+      AttnArgs a{};
+      a.Q = e->qkv_d;
+      a.K = e->qkv_d + dt;
+      a.V = e->qkv_d + 2 * dt;
+      a.q_bs = a.k_bs = a.v_bs = (long)n * 6 * dt;
+      a.q_rs = a.k_rs = a.v_rs = 6 * dt;
+      a.O = e->att_d;
+      a.o_bs = (long)n * 2 * dt;
+      a.o_rs = 2 * dt;
+      a.split = 1;
+      a.q_lo = a.k_lo = a.v_lo = 3 * dt;
+      a.o_lo = dt;
+      a.nq = n;
+      a.nk = n;
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 1;
+      HIPCHK(launch_attention(a, s));
+    }
+    WCA_TRY(mm(e->att_d, 2 * dt, w.out_w, l.out_b, e->xd, dt, dt, 2 * dt, 0, 2, 0, 2));
+    WCA_TRY(ln(l.lnc_g, l.lnc_b));
+    WCA_TRY(mm(e->xdn, 2 * dt, w.cq_w, l.cq_b, e->q_d, 2 * dt, dt, 2 * dt, 0, 0, dt, 2));
+    {
+      AttnArgs a{};
+      a.Q = e->q_d;
+      a.q_bs = (long)n * 2 * dt;
+      a.q_rs = 2 * dt;
+      a.K = kvbuf + (size_t)(2 * li) * dt;
+      a.V = kvbuf + (size_t)(2 * li + 1) * dt;
+      a.k_bs = a.v_bs = (long)N_CTX * kv_ld;
+      a.k_rs = a.v_rs = kv_ld;
+      a.O = e->att_d;
+      a.o_bs = (long)n * 2 * dt;
+      a.o_rs = 2 * dt;
+      a.split = 1;
+      a.q_lo = dt;
+      a.k_lo = a.v_lo = kv_lo;
+      a.o_lo = dt;
+      a.cap = cap ? cap + (size_t)li * H * n * Fpad : nullptr;
+      a.cap_bs = (long)L * H * n * Fpad;
+      a.cap_hs = (long)n * Fpad;
+      a.cap_ld = Fpad;
+      a.cap_cols = Fcap;
+      a.nq = n;
+      a.nk = N_CTX;
+      a.H = H;
+      a.B = B;
+      a.scale = scale;
+      a.causal = 0;
+      HIPCHK(launch_attention(a, s));
+    }
+    if (li == L - 1 && !logits_out) break;
+    WCA_TRY(mm(e->att_d, 2 * dt, w.co_w, l.co_b, e->xd, dt, dt, 2 * dt, 0, 2, 0, 2));
+    WCA_TRY(ln(l.ln2_g, l.ln2_b));
+    WCA_TRY(mm(e->xdn, 2 * dt, w.fc1_w, l.fc1_b, e->hid_d, 8 * dt, 4 * dt, 2 * dt, 1, 0, 4 * dt, 2));
+    WCA_TRY(mm(e->hid_d, 8 * dt, w.fc2_w, l.fc2_b, e->xd, dt, dt, 8 * dt, 0, 2, 0, 2));
+  }
+  if (logits_out) {
+    WCA_TRY(ln(e->lnf_g, e->lnf_b));
+    WCA_TRY(mm(e->xdn, 2 * dt, e->sw.tok_emb, nullptr, logits_out, D.n_vocab, D.n_vocab, 2 * dt, 0, 1, 0, 3));
+  }
   return WCA_OK;
 }
 
@@ -664,6 +871,7 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
   if (!s) s = e->stream;
   if (!kvbuf) kvbuf = e->kv;
+  if (e->split) return run_decoder_split(e, tokens_dev, B, n, cap, Fpad, Fcap, logits_out, s, kvbuf);
   const int M = B * n;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
   HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
@@ -748,7 +956,9 @@ int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, c
   half_t* att_d = e->att_d + (size_t)b0 * dt;
   half_t* q_d = e->q_d + (size_t)b0 * dt;
   half_t* hid_d = e->hid_d + (size_t)b0 * 4 * dt;
-  const half_t* kvb = kvbuf + (size_t)b0 * N_CTX * L * 2 * dt;
+  // split mode: the cross-K/V rows are [hi | lo]; the greedy pre-pass (whisper.decode runs in fp16 itself) reads the hi halves
+  const int kv_ld = (e->split ? 2 : 1) * L * 2 * dt;
+  const half_t* kvb = kvbuf + (size_t)b0 * N_CTX * kv_ld;
   if (phase == -2 || phase == -1)
     HIPCHK(launch_embed_step(tokens + (size_t)b0 * T_max, T_max, t, e->tok_emb, e->dec_pos, xd, B, dt, D.n_vocab, s));
   for (int li = 0; li < L; ++li) {
@@ -786,8 +996,8 @@ int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, c
       a.q_rs = dt;
       a.K = kvb + (size_t)(2 * li) * dt;
       a.V = kvb + (size_t)(2 * li + 1) * dt;
-      a.k_bs = a.v_bs = (long)N_CTX * L * 2 * dt;
-      a.k_rs = a.v_rs = L * 2 * dt;
+      a.k_bs = a.v_bs = (long)N_CTX * kv_ld;
+      a.k_rs = a.v_rs = kv_ld;
       a.O = att_d;
       a.o_bs = dt;
       a.o_rs = dt;
@@ -813,7 +1023,7 @@ int check_ready(wca_engine* e) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   if (!e->finalized) return fail(WCA_ERR_STATE, "weights not finalized (call wca_finalize_weights)");
   HIPCHK(hipSetDevice(e->device));
-  return WCA_OK;
+  return ensure_split_weights(e);  // split mode: the K-doubled weight copies are current (no-op otherwise)
 }
 
 // stage per-utterance metadata into the next device slot: rows = {n_samples, n_tok, n_frames, dtwN}
@@ -844,7 +1054,9 @@ int run_logmel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const in
   a.twiddle = e->twiddle;
   a.mel_out = mel_out;
   a.mel_tm = want_tm ? e->mel_tm : nullptr;
-  a.n_mels_pad = e->dims.n_mels;
+  a.n_mels_pad = (e->split ? 2 : 1) * e->dims.n_mels;
+  a.tm_lo = e->split ? e->dims.n_mels : 0;
+  a.precise = e->split ? 1 : 0;
   a.scratch = e->mel_scratch;
   a.gmax = e->gmax;
   a.n_mels = e->dims.n_mels;
@@ -854,12 +1066,37 @@ int run_logmel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const in
 }
 
 // mel f32 [B][n_mels][3000] -> time-major f16 image used by the conv GEMM
-__global__ void mel_to_tm_kernel(const float* __restrict__ mel, half_t* __restrict__ tm, int n_mels, int B) {
+// row = row length of the image (n_mels, or 2 n_mels in split mode: lo = f16(v - hi) at column lo_off + m)
+__global__ void mel_to_tm_kernel(const float* __restrict__ mel, half_t* __restrict__ tm, int n_mels, int B, int row, int lo_off) {
   const int b = blockIdx.y;
   const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e0 >= (long)n_mels * N_FRAMES) return;
   const int t = (int)(e0 / n_mels), m = (int)(e0 - (long)t * n_mels);
-  tm[((long)b * (N_FRAMES + 2) + t + 1) * n_mels + m] = (half_t)mel[((long)b * n_mels + m) * N_FRAMES + t];
+  const float v = mel[((long)b * n_mels + m) * N_FRAMES + t];
+  const half_t hv = (half_t)v;
+  half_t* o = tm + ((long)b * (N_FRAMES + 2) + t + 1) * row + m;
+  o[0] = hv;
+  if (lo_off) o[lo_off] = (half_t)(v - (float)hv);
+}
+
+int mel_to_tm(wca_engine* e, const float* mel_dev, int batch) {
+  const wca_model_dims& D = e->dims;
+  const size_t nel = (size_t)D.n_mels * N_FRAMES;
+  dim3 grid((unsigned)((nel + 255) / 256), batch);
+  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch, (e->split ? 2 : 1) * D.n_mels,
+                     e->split ? D.n_mels : 0);
+  HIPCHK(hipGetLastError());
+  return WCA_OK;
+}
+
+// out[r][c] = hi + lo of a split row [hi(d) | lo(d)]
+__global__ void widen_split_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t rows, int d) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t st = (size_t)gridDim.x * blockDim.x;
+  for (; i < rows * d; i += st) {
+    const size_t r = i / d, c = i - r * d;
+    out[i] = (float)in[r * 2 * d + c] + (float)in[r * 2 * d + d + c];
+  }
 }
 
 __global__ void widen_kernel(const half_t* __restrict__ in, float* __restrict__ out, size_t n) {
@@ -893,10 +1130,7 @@ int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_
     int rc = run_logmel(e, pcm_dev, pcm_stride, n_samples_dev, batch, nullptr, true);
     if (rc) return rc;
   } else {
-    const size_t nel = (size_t)D.n_mels * N_FRAMES;
-    dim3 grid((unsigned)((nel + 255) / 256), batch);
-    hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
-    HIPCHK(hipGetLastError());
+    if (int mr = mel_to_tm(e, mel_dev, batch)) return mr;
   }
   record(e, 1);
   e->ln_err = e->err_dev + 1 + slot;
@@ -1098,6 +1332,7 @@ void wca_engine_destroy(wca_engine* e) {
                      &e->jump, &e->tmp0, &e->tmp1})
     g->release();
   if (e->wslab) (void)hipFree(e->wslab);
+  if (e->wslab2) (void)hipFree(e->wslab2);
   if (e->aslab) (void)hipFree(e->aslab);
   if (e->meta_host) (void)hipHostFree(e->meta_host);
   if (e->err_host) (void)hipHostFree(e->err_host);
@@ -1200,6 +1435,45 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   return WCA_OK;
 }
 
+int wca_set_precision(wca_engine* e, int mode) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (mode != WCA_PRECISION_F16 && mode != WCA_PRECISION_SPLIT) return fail(WCA_ERR_INVALID, "precision mode %d", mode);
+  const bool want = mode == WCA_PRECISION_SPLIT;
+  if (want == e->split) return WCA_OK;
+  if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the batches in flight before changing the precision mode");
+  for (auto& st : e->enc_q)
+    if (!st.decoded) return fail(WCA_ERR_STATE, "an encoded batch is waiting: consume it before changing the precision mode");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream2));
+  HIPCHK(hipStreamSynchronize(e->stream3));
+  for (auto& st : e->enc_q) e->slot_busy[st.slot] = false;  // decoded-but-never-aligned states die with the arena
+  e->enc_q.clear();
+  // the activation arena is laid out per mode (operand buffers are twice as wide in split mode): re-create it
+  HIPCHK(hipFree(e->aslab));
+  e->aslab = nullptr;
+  if (e->wslab2) {
+    HIPCHK(hipFree(e->wslab2));
+    e->wslab2 = nullptr;
+  }
+  e->split = want;
+  const size_t abytes = layout_arena(e, nullptr);
+  HIPCHK(hipMalloc((void**)&e->aslab, abytes));
+  HIPCHK(hipMemset(e->aslab, 0, abytes));  // zero pad rows of mel_tm / h1pad, counters, flags and all slack
+  layout_arena(e, e->aslab);
+  e->ln_err = nullptr;
+  if (want) {
+    const size_t wbytes = layout_split_weights(e, nullptr);
+    HIPCHK(hipMalloc((void**)&e->wslab2, wbytes));
+    HIPCHK(hipMemset(e->wslab2, 0, wbytes));  // K padding of the conv1 copy stays zero
+    layout_split_weights(e, e->wslab2);
+    e->sw_dirty = true;  // built on the next entry point that runs the model (after the weights are final)
+  }
+  return WCA_OK;
+}
+
+int wca_get_precision(wca_engine* e) { return (e && e->split) ? WCA_PRECISION_SPLIT : WCA_PRECISION_F16; }
+
 int wca_set_fuse_ln(wca_engine* e, int on) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   e->fuse_ln = on != 0;
@@ -1289,7 +1563,10 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     rc = load_block_tensor(e, is_dec ? e->dec[li] : e->enc[li], is_dec, li, name.substr(dot + 1), p, dtype, n, is_dec ? dt : d);
   }
 #undef WANTN
-  if (rc == WCA_OK) e->loaded.insert(name);
+  if (rc == WCA_OK) {
+    e->loaded.insert(name);
+    e->sw_dirty = true;
+  }
   return rc < 0 ? rc : WCA_OK;  // unknown names (e.g. alignment_heads) are ignored
 }
 
@@ -1352,10 +1629,7 @@ int wca_get_attentions(wca_engine* e, const float* mel_dev, const int64_t* token
   int* rows[4];
   rc = stage_meta(e, batch, nullptr, ntok.data(), max_frames_host, nullptr, rows);
   if (rc) return rc;
-  const size_t nel = (size_t)D.n_mels * N_FRAMES;
-  dim3 grid((unsigned)((nel + 255) / 256), batch);
-  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
-  HIPCHK(hipGetLastError());
+  if ((rc = mel_to_tm(e, mel_dev, batch))) return rc;
   // cross-K/V go into a slot no queued batch (wca_encode_batch / wca_greedy_decode / an un-fetched alignment) still needs
   const int slot = take_kv_slot(e);
   if (slot < 0) return fail(WCA_ERR_STATE, "both cross-K/V slots hold live batches: fetch or consume one first");
@@ -2102,6 +2376,10 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   g.K = K;
   g.gelu = gelu;
   g.out_mode = out_mode & 0xff;
+  if (g.out_mode == 4) {  // f16 pair output: c [M][2N], hi at column n, lo at column N + n
+    g.ldc = 2 * N;
+    g.c_lo = N;
+  }
   g.force_tile = (out_mode >> 8) & 0xfff;  // 0 auto / 128 / 256 / 257 (persistent) / 258 (one tile per workgroup)
   g.supertile = out_mode >> 20;             // 0 = launch_gemm's choice (tools: tile-order experiments)
   g.sk_part = e->sk_big[0];                  // few tiles, K >= 2048, out_mode 2: split-K with the engine's workspace, as the encoder does
@@ -2263,6 +2541,41 @@ int wca_test_attention(wca_engine* e, const void* q, const void* k, const void* 
   return test_attention_impl(e, q, k, v, o, cap_dev, cap_ld, cap_cols, B, H, nq, nk, causal, nullptr);
 }
 
+int wca_test_attention_split(wca_engine* e, const void* q2, const void* k2, const void* v2, void* o2, float* cap_dev, int cap_ld, int cap_cols,
+                             int B, int H, int nq, int nk, int causal) {
+  if (!e || !q2 || !k2 || !v2 || !o2) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  AttnArgs a{};
+  const int d = H * 64;
+  a.Q = (const half_t*)q2;
+  a.q_bs = (long)nq * 2 * d;
+  a.q_rs = 2 * d;
+  a.K = (const half_t*)k2;
+  a.k_bs = (long)nk * 2 * d;
+  a.k_rs = 2 * d;
+  a.V = (const half_t*)v2;
+  a.v_bs = (long)nk * 2 * d;
+  a.v_rs = 2 * d;
+  a.O = (half_t*)o2;
+  a.o_bs = (long)nq * 2 * d;
+  a.o_rs = 2 * d;
+  a.split = 1;
+  a.q_lo = a.k_lo = a.v_lo = a.o_lo = d;
+  a.cap = cap_dev;
+  a.cap_bs = (long)H * nq * cap_ld;
+  a.cap_hs = (long)nq * cap_ld;
+  a.cap_ld = cap_ld;
+  a.cap_cols = cap_cols;
+  a.nq = nq;
+  a.nk = nk;
+  a.H = H;
+  a.B = B;
+  a.scale = 0.125f;
+  a.causal = causal & 1;
+  HIPCHK(launch_attention(a, e->stream));
+  return WCA_OK;
+}
+
 int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nk,
                                unsigned long long* dbg_dev) {
   if (!dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
@@ -2301,21 +2614,29 @@ int wca_test_layernorm(wca_engine* e, const float* x, const float* g, const floa
   return WCA_OK;
 }
 
+int wca_test_layernorm_split(wca_engine* e, const float* x, const float* g, const float* b, void* out2, int rows, int d) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(launch_layernorm_f16(x, g, b, (half_t*)out2, rows, d, 1e-5f, e->stream, 2 * d, d));
+  return WCA_OK;
+}
+
 int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_out_dev) {
   int rc = check_ready(e);
   if (rc) return rc;
   if ((rc = join_phase2(e))) return rc;
   if (batch < 1 || batch > e->max_batch) return fail(WCA_ERR_INVALID, "batch %d outside [1,%d]", batch, e->max_batch);
   const wca_model_dims& D = e->dims;
-  const size_t nel = (size_t)D.n_mels * N_FRAMES;
-  dim3 grid((unsigned)((nel + 255) / 256), batch);
-  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch);
-  HIPCHK(hipGetLastError());
+  if ((rc = ensure_split_weights(e))) return rc;
+  if ((rc = mel_to_tm(e, mel_dev, batch))) return rc;
   rc = run_encoder(e, batch);
   if (rc) return rc;
-  // xn holds ln_post(x) in f16; widen for the caller
+  // xn holds ln_post(x) in f16 (split mode: hi + lo pairs); widen for the caller
   const size_t n = (size_t)batch * N_CTX * D.n_audio_state;
-  hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, n);
+  if (e->split)
+    hipLaunchKernelGGL(widen_split_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, (size_t)batch * N_CTX, D.n_audio_state);
+  else
+    hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, n);
   HIPCHK(hipGetLastError());
   return WCA_OK;
 }

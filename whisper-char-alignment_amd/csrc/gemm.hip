@@ -57,7 +57,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
       for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
     if (GELU) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+      for (int j = 0; j < 16; ++j) v[j] = (OUT_MODE == 4) ? gelu_erf_exact(v[j]) : gelu_erf(v[j]);
     }
     if (a.pos != nullptr) {
       const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nb;
@@ -73,7 +73,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
     } else {
       coff = (long)m * a.ldc;
     }
-    if (OUT_MODE == 0) {
+    if (OUT_MODE == 0 || OUT_MODE == 4) {
       half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
       if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
         half8 h0, h1;
@@ -84,10 +84,24 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
         }
         reinterpret_cast<half8*>(cp)[0] = h0;
         reinterpret_cast<half8*>(cp)[1] = h1;
+        if (OUT_MODE == 4) {  // lo halves (c_lo is a multiple of 8 elements: the same 16-byte alignment)
+          half8 l0, l1;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            l0[j] = (half_t)(v[j] - (float)h0[j]);
+            l1[j] = (half_t)(v[8 + j] - (float)h1[j]);
+          }
+          reinterpret_cast<half8*>(cp + a.c_lo)[0] = l0;
+          reinterpret_cast<half8*>(cp + a.c_lo)[1] = l1;
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-          if (nb + j < a.N) cp[j] = (half_t)v[j];
+          if (nb + j < a.N) {
+            const half_t hv = (half_t)v[j];
+            cp[j] = hv;
+            if (OUT_MODE == 4) cp[a.c_lo + j] = (half_t)(v[j] - (float)hv);
+          }
       }
     } else {
       float* cp = reinterpret_cast<float*>(a.C) + coff + nb;
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   //   f16 out: lane fg owns columns fg*8 .. +7 and 32 + fg*8 .. +7   -> n = (nt>>1)*32 + (i>>2)*8 + (nt&1)*4 + (i&3)
   //   f32 out: lane fg owns columns nt*16 + fg*4 .. +3 (natural)      -> n = nt*16 + i
   const int nt_r = rho >> 4, i_r = rho & 15;
-  const int wsrc_row = (OUT_MODE == 0 || OUT_MODE == 3) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
+  const int wsrc_row = (OUT_MODE == 0 || OUT_MODE == 3 || OUT_MODE == 4) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
   // per-lane byte offsets inside a tile (tile base and K offset are wave-uniform and added per request)
   const unsigned va = (unsigned)(rho * a.lda + c0 * 8) * 2u;
   const unsigned vw = (unsigned)(wsrc_row * a.ldw + c0 * 8) * 2u;
@@ -797,7 +811,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.K <= 0 || (a.K % BK) != 0) return hipErrorInvalidValue;
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
   // M <= 64 (greedy-decode steps): weight-streaming skinny kernel; force_tile 64 forces it, 128 etc. bypass it
-  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr) {
+  if (a.out_mode == 4 && (a.c_lo <= 0 || (a.c_lo & 7))) return hipErrorInvalidValue;
+  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.out_mode != 4) {
     const dim3 sgrid((unsigned)((a.N + 15) / 16)), sblock(256);
 #define WCA_LAUNCH_SK(OM, G) hipLaunchKernelGGL((gemm_skinny_f16_kernel<OM, G>), sgrid, sblock, 0, s, a)
     if (a.out_mode == 0) {
@@ -927,6 +942,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   } else if (a.out_mode == 2) {
     if (a.gelu) return hipErrorInvalidValue;
     WCA_LAUNCH(2, false);
+  } else if (a.out_mode == 4) {
+    if (a.gelu) WCA_LAUNCH(4, true); else WCA_LAUNCH(4, false);
   } else {
     return hipErrorInvalidValue;
   }

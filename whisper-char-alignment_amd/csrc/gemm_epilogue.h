@@ -16,7 +16,7 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
   // column of value (nt, r = 0) relative to nbase
   int col[4];
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) col[nt] = (OUT_MODE == 0) ? ((nt >> 1) * 32 + fg * 8 + (nt & 1) * 4) : (nt * 16 + fg * 4);
+  for (int nt = 0; nt < 4; ++nt) col[nt] = (OUT_MODE == 0 || OUT_MODE == 4) ? ((nt >> 1) * 32 + fg * 8 + (nt & 1) * 4) : (nt * 16 + fg * 4);
   // bias_l: this wave's 64 bias values in LDS (zero where there is no bias / past N)
   float bv[16];
 #pragma unroll
@@ -85,7 +85,7 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
     if (m >= a.M) continue;
     if (GELU) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = gelu_erf(v[j]);
+      for (int j = 0; j < 16; ++j) v[j] = (OUT_MODE == 4) ? gelu_erf_exact(v[j]) : gelu_erf(v[j]);
     }
     if (a.pos != nullptr) {
       const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nbase;
@@ -103,7 +103,7 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
     } else {
       coff = (long)m * a.ldc;
     }
-    if (OUT_MODE == 0) {
+    if (OUT_MODE == 0 || OUT_MODE == 4) {
       half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nbase;
       if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 8) & 15) == 0)) {
 #pragma unroll
@@ -112,13 +112,23 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
 #pragma unroll
           for (int j = 0; j < 8; ++j) o[j] = (half_t)v[hh * 8 + j];
           *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
+          if (OUT_MODE == 4) {  // lo halves, c_lo elements further (a multiple of 8: same alignment)
+            half8 ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ol[j] = (half_t)(v[hh * 8 + j] - (float)o[j]);
+            *reinterpret_cast<half8*>(cp + a.c_lo + hh * 32 + fg * 8) = ol;
+          }
         }
       } else {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (nbase + col[nt] + r < a.N) cp[col[nt] + r] = (half_t)v[nt * 4 + r];
+            if (nbase + col[nt] + r < a.N) {
+              const half_t hv = (half_t)v[nt * 4 + r];
+              cp[col[nt] + r] = hv;
+              if (OUT_MODE == 4) cp[a.c_lo + col[nt] + r] = (half_t)(v[nt * 4 + r] - (float)hv);
+            }
       }
     } else {
       float* cp = reinterpret_cast<float*>(a.C) + coff + nbase;

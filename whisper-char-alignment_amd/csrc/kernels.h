@@ -23,11 +23,14 @@ struct GemmArgs {
   int ldc;
   int c_rows_per_batch;    // 0 => flat
   long c_batch_stride;     // elements
+  long c_lo;               // out_mode 4: elements from a value's hi half to its lo half (a multiple of 8)
   const float* pos;        // optional additive table pos[(m % pos_period)][N] (f32), or nullptr
   int pos_period;
   int M, N, K;             // K % 64 == 0
   int gelu;                // apply exact (erf) GELU after bias
   int out_mode;            // 0: store f16, 1: store f32, 2: f32 accumulate (C += result),
+                           // 4: store the value as an f16 PAIR hi = f16(v) at C, lo = f16(v - hi) at C + c_lo (reference-precision
+                           //    "split" mode, see wca_set_precision; GELU is then the erff form, not the 1.5e-7 polynomial),
                            // 3: f32 accumulate + LayerNorm of the updated row -> ln_out (f16); the row statistics are
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
@@ -85,12 +88,19 @@ struct AttnArgs {
   int causal;
   unsigned long long* dbg;                 // diagnostic builds only (s_memtime stamps)
   int variant;                             // 0 auto, 1 force the 16x16x32 kernel, 2 force the 32x32x16 kernel (tests)
+  // split-f16 operands (reference-precision mode): every value x is carried as hi = f16(x), lo = f16(x - hi). The pointers above
+  // address the hi halves; the lo half of an element lives `*_lo` elements further (same strides). split != 0 selects
+  // attn_split_kernel: S = Qhi.Khi + Qhi.Klo + Qlo.Khi, O = Phi.Vhi + Phi.Vlo + Plo.Vhi, fp32 softmax on the exact logits.
+  int split;
+  long q_lo, k_lo, v_lo, o_lo;
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s);  // attention_split.hip (launch_attention forwards a.split != 0 here)
 
 // ---------------------------------------------------------------- small ops (elementwise.hip)
+// ld_out: elements between output rows (0 = d). lo_off != 0: split output, hi = f16(y) at out, lo = f16(y - hi) at out + lo_off
 hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float* beta, half_t* out,
-                                int rows, int d, float eps, hipStream_t s);
+                                int rows, int d, float eps, hipStream_t s, int ld_out = 0, long lo_off = 0);
 // x[b*n + i][:] = tok_emb[tokens[b*n+i]][:] + pos_emb[i][:]
 // ids outside [0, n_vocab) are embedded as token 0 and raise *err (device int, nullable)
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x,
@@ -135,6 +145,8 @@ struct LogMelArgs {
   float* mel_out;          // [B][n_mels][3000] f32 (may be nullptr)
   half_t* mel_tm;          // [B][3002][n_mels_pad] f16 time-major, rows 0 and 3001 zero (may be nullptr)
   int n_mels_pad;          // row length of mel_tm
+  int tm_lo;               // != 0: mel_tm carries split values, hi at column m, lo = f16(v - hi) at column tm_lo + m
+  int precise;             // != 0: the DFT and the filterbank sums accumulate in f64 (reference-precision mode)
   float* scratch;          // [B][n_mels][3000] raw log10 values (required)
   unsigned* gmax;          // [B] ordered-int encoded running max (required)
   int n_mels, B;

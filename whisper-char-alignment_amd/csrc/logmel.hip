@@ -70,17 +70,34 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogMelArgs a) {
   __syncthreads();
   if (tid < NBIN) {
     const int k = tid;
-    float re = s_e[0] + ((k & 1) ? -s_e[NFFT / 2] : s_e[NFFT / 2]);
-    float im = 0.f;
-    int idx = 0;
-    for (int n = 1; n < NFFT / 2; ++n) {
-      idx += k;
-      if (idx >= NFFT) idx -= NFFT;
-      const f32x2 tw = s_tw[idx];
-      re = fmaf(s_e[n], tw[0], re);
-      im = fmaf(s_o[n], tw[1], im);
+    if (a.precise) {
+      // reference-precision mode: f64 accumulation of the f32 products (the reference's FFT is accurate to ~1e-7 of the frame's
+      // magnitude; a 199-term f32 sum is not). Twiddles and folded samples stay the f32 values above.
+      double re = (double)s_e[0] + ((k & 1) ? -(double)s_e[NFFT / 2] : (double)s_e[NFFT / 2]);
+      double im = 0.0;
+      int idx = 0;
+      for (int n = 1; n < NFFT / 2; ++n) {
+        idx += k;
+        if (idx >= NFFT) idx -= NFFT;
+        const f32x2 tw = s_tw[idx];
+        re = fma((double)s_e[n], (double)tw[0], re);
+        im = fma((double)s_o[n], (double)tw[1], im);
+      }
+      const float ref = (float)re, imf = (float)im;  // torch.stft returns complex64; abs()**2 is then f32 arithmetic
+      s_pow[k] = ref * ref + imf * imf;
+    } else {
+      float re = s_e[0] + ((k & 1) ? -s_e[NFFT / 2] : s_e[NFFT / 2]);
+      float im = 0.f;
+      int idx = 0;
+      for (int n = 1; n < NFFT / 2; ++n) {
+        idx += k;
+        if (idx >= NFFT) idx -= NFFT;
+        const f32x2 tw = s_tw[idx];
+        re = fmaf(s_e[n], tw[0], re);
+        im = fmaf(s_o[n], tw[1], im);
+      }
+      s_pow[k] = re * re + im * im;
     }
-    s_pow[k] = re * re + im * im;
   }
   __syncthreads();
   float lv = -INFINITY;
@@ -127,7 +144,10 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(LogMelArgs a) {
       const int t = t0 + tt;
       if (t < NFRAMES) {
         const float v = (t < na) ? sc[(long)m * NFRAMES + t] : -10.0f;
-        mt[(long)(t + 1) * a.n_mels_pad + m] = (half_t)((fmaxf(v, floorv) + 4.0f) * 0.25f);
+        const float y = (fmaxf(v, floorv) + 4.0f) * 0.25f;
+        const half_t hv = (half_t)y;
+        mt[(long)(t + 1) * a.n_mels_pad + m] = hv;
+        if (a.tm_lo) mt[(long)(t + 1) * a.n_mels_pad + a.tm_lo + m] = (half_t)(y - (float)hv);
       }
     }
   }

@@ -77,6 +77,18 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.f) - fabsf(h);
 }
 
+// Reference-precision ("split") mode: torch's erf GELU, x * 0.5 * (1 + erf(x / sqrt 2)), with the device library's erff
+// (<= 2 ulp). The polynomial above is exact to the f16 store that follows it in the default mode; here the value is kept
+// to ~22 bits, so its 3e-7 absolute error would show.
+__device__ __forceinline__ float gelu_erf_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// x -> (hi, lo) with hi = f16(x), lo = f16(x - hi): x = hi + lo up to 2^-22 |x| (lo is exact in f32; it rounds to f16 with
+// 11 more bits, or to the f16 subnormal grid, 6e-8 absolute, for |x| below ~0.1)
+__device__ __forceinline__ void split_f16(float x, half_t& hi, half_t& lo) {
+  hi = (half_t)x;
+  lo = (half_t)(x - (float)hi);
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: blocks that share an XCD
 // (id % 8 equal) get a contiguous range of logical ids, so neighbouring tiles hit one L2.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {

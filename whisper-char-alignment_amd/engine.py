@@ -402,8 +402,22 @@ class WhisperAMD:
         _lib.check(self._lib.wca_last_kernel_ms(self._h, _lib.SITES[site], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return n.value, ms.value, fl.value, by.value
 
+    def set_precision(self, mode):
+        """'f16' (default): operands rounded to f16 once, fp32 accumulation. 'split': reference precision -- every operand as an
+        f16 (hi, lo) pair against the exact f16 weights, three-pass attention (wca.h: wca_set_precision). No batch may be in
+        flight; the activation arena is re-created."""
+        modes = {"f16": 0, "split": 1}
+        if mode not in modes:
+            raise ValueError("precision must be 'f16' or 'split'")
+        _lib.check(self._lib.wca_set_precision(self._h, modes[mode]))
+        return self
+
+    @property
+    def precision(self):
+        return "split" if self._lib.wca_get_precision(self._h) == 1 else "f16"
+
     def set_fuse_ln(self, on):
-        """LayerNorm in the residual GEMMs' epilogue (default) or as separate launches."""
+        """LayerNorm in the residual GEMMs' epilogue, or as separate launches (the default)."""
         _lib.check(self._lib.wca_set_fuse_ln(self._h, 1 if on else 0))
 
     def set_overlap(self, on):
