@@ -66,12 +66,14 @@ def test_split_gemm_is_fp32_accurate(eng, lib, wca, M, N, K, tile):
     err = (out.cpu().double() - ref).abs().max().item()
     assert err < 4e-7 * scale, (err, scale)
     # pair output with the erf GELU (out_mode 4): hi + lo against float64 gelu, fp32 accuracy of the stored value
-    out2 = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device="cuda")
-    wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a2), _vp(w2), _vp(bd), _vp(out2), M, N, 2 * K, 1, 4 | (tile << 8)))
-    torch.cuda.synchronize()
-    gref = torch.nn.functional.gelu(ref)
-    gerr = (_join(out2.cpu()) - gref).abs().max().item()
-    assert gerr < 4e-7 * scale + 3e-7 * gref.abs().max().item(), gerr
+    # (the lo half sits N elements after the hi half: the 16-byte stores need N % 8 == 0, as every width of the model is)
+    if N % 8 == 0:
+        out2 = torch.full((M, 2 * N), float("nan"), dtype=torch.float16, device="cuda")
+        wca._lib.check(lib.wca_test_gemm(eng._h, _vp(a2), _vp(w2), _vp(bd), _vp(out2), M, N, 2 * K, 1, 4 | (tile << 8)))
+        torch.cuda.synchronize()
+        gref = torch.nn.functional.gelu(ref)
+        gerr = (_join(out2.cpu()) - gref).abs().max().item()
+        assert gerr < 4e-7 * scale + 3e-7 * gref.abs().max().item(), gerr
     # contrast: the default mode on the f16-rounded activations
     outh = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
     ah = a.half().cuda()
@@ -179,10 +181,11 @@ def test_split_forward_vs_oracle_small_dims(wca):
     l_err = ((logits.cpu() - rlogits).abs().max() / rlogits.abs().max()).item()
     w16_err = (w16.cpu() - rw).abs().max().item()
     print("split vs oracle: log-mel %.2e, encoder %.2e, maps %.2e (f16 mode %.2e), logits %.2e rel" % (mel_err, enc_err, w_err, w16_err, l_err))
-    assert mel_err < 2e-5
-    assert enc_err < 5e-5          # LayerNorm-ed outputs, O(1)
-    assert w_err < 5e-6            # softmaxed maps in [0, 1]
-    assert l_err < 2e-5
+    # measured on MI355X: log-mel 2.0e-6, encoder 1.2e-6, maps 2.3e-7 (default mode: 1.6e-4), logits 8e-7
+    assert mel_err < 1e-5
+    assert enc_err < 1e-5          # LayerNorm-ed outputs, O(1)
+    assert w_err < 2e-6            # softmaxed maps in [0, 1]
+    assert l_err < 1e-5
     words, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=4)
     rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 4)
     assert words == rwords and np.array_equal(st, rst) and np.array_equal(en, ren)

@@ -237,11 +237,11 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
         half8 fh, fl;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p0 = st[s][2 * k2][r], p1 = st[s][2 * k2 + 1][r];
-          fh[r] = (half_t)p0;
-          fl[r] = (half_t)(p0 - (float)fh[r]);
-          fh[4 + r] = (half_t)p1;
-          fl[4 + r] = (half_t)(p1 - (float)fh[4 + r]);
+          const HalfPair p0 = split_pair(st[s][2 * k2][r]), p1 = split_pair(st[s][2 * k2 + 1][r]);
+          fh[r] = p0.hi;
+          fl[r] = p0.lo;
+          fh[4 + r] = p1.hi;
+          fl[4 + r] = p1.lo;
         }
         ph[s][k2] = fh;
         pl[s][k2] = fl;
@@ -288,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
       half4 oh, ol;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float o = ot[s][dt][r] * inv;
-        oh[r] = (half_t)o;
-        ol[r] = (half_t)(o - (float)oh[r]);
+        const HalfPair pr = split_pair(ot[s][dt][r] * inv);
+        oh[r] = pr.hi;
+        ol[r] = pr.lo;
       }
       *reinterpret_cast<half4*>(op + dt * 16) = oh;
       *reinterpret_cast<half4*>(op + a.o_lo + dt * 16) = ol;

@@ -49,8 +49,13 @@ __global__ __launch_bounds__(256) void layernorm_f16_v4_kernel(const float* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float y = (v[i][j] - mean) * rstd * g[j] + bb[j];
-      o[j] = (half_t)y;
-      if (SPLIT) ol[j] = (half_t)(y - (float)o[j]);
+      if (SPLIT) {
+        const HalfPair pr = split_pair(y);
+        o[j] = pr.hi;
+        ol[j] = pr.lo;
+      } else {
+        o[j] = (half_t)y;
+      }
     }
     o4[i * 64 + lane] = o;
     if (SPLIT) l4[i * 64 + lane] = ol;
@@ -90,15 +95,19 @@ __global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __re
     const f32x2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
     const float y0 = (v[i][0] - mean) * rstd * g[0] + bb[0], y1 = (v[i][1] - mean) * rstd * g[1] + bb[1];
     half2_ o;
-    o[0] = (half_t)y0;
-    o[1] = (half_t)y1;
-    o2[i * 64 + lane] = o;
     if (SPLIT) {
+      const HalfPair p0 = split_pair(y0), p1 = split_pair(y1);
       half2_ ol;
-      ol[0] = (half_t)(y0 - (float)o[0]);
-      ol[1] = (half_t)(y1 - (float)o[1]);
+      o[0] = p0.hi;
+      o[1] = p1.hi;
+      ol[0] = p0.lo;
+      ol[1] = p1.lo;
       l2[i * 64 + lane] = ol;
+    } else {
+      o[0] = (half_t)y0;
+      o[1] = (half_t)y1;
     }
+    o2[i * 64 + lane] = o;
   }
 }
 

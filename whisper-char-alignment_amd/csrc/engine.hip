@@ -1076,7 +1076,7 @@ __global__ void mel_to_tm_kernel(const float* __restrict__ mel, half_t* __restri
   const half_t hv = (half_t)v;
   half_t* o = tm + ((long)b * (N_FRAMES + 2) + t + 1) * row + m;
   o[0] = hv;
-  if (lo_off) o[lo_off] = (half_t)(v - (float)hv);
+  if (lo_off) o[lo_off] = (half_t)(v - (float)hv);  // (v is a loaded value: nothing to contract into either conversion)
 }
 
 int mel_to_tm(wca_engine* e, const float* mel_dev, int batch) {

@@ -76,21 +76,23 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
     if (OUT_MODE == 0 || OUT_MODE == 4) {
       half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
       if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
-        half8 h0, h1;
+        half8 h0, h1, l0, l1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          h0[j] = (half_t)v[j];
-          h1[j] = (half_t)v[8 + j];
+          if (OUT_MODE == 4) {
+            const HalfPair p0 = split_pair(v[j]), p1 = split_pair(v[8 + j]);
+            h0[j] = p0.hi;
+            l0[j] = p0.lo;
+            h1[j] = p1.hi;
+            l1[j] = p1.lo;
+          } else {
+            h0[j] = (half_t)v[j];
+            h1[j] = (half_t)v[8 + j];
+          }
         }
         reinterpret_cast<half8*>(cp)[0] = h0;
         reinterpret_cast<half8*>(cp)[1] = h1;
         if (OUT_MODE == 4) {  // lo halves (c_lo is a multiple of 8 elements: the same 16-byte alignment)
-          half8 l0, l1;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            l0[j] = (half_t)(v[j] - (float)h0[j]);
-            l1[j] = (half_t)(v[8 + j] - (float)h1[j]);
-          }
           reinterpret_cast<half8*>(cp + a.c_lo)[0] = l0;
           reinterpret_cast<half8*>(cp + a.c_lo)[1] = l1;
         }
@@ -98,9 +100,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
 #pragma unroll
         for (int j = 0; j < 16; ++j)
           if (nb + j < a.N) {
-            const half_t hv = (half_t)v[j];
-            cp[j] = hv;
-            if (OUT_MODE == 4) cp[a.c_lo + j] = (half_t)(v[j] - (float)hv);
+            if (OUT_MODE == 4) {
+              const HalfPair pr = split_pair(v[j]);
+              cp[j] = pr.hi;
+              cp[a.c_lo + j] = pr.lo;
+            } else {
+              cp[j] = (half_t)v[j];
+            }
           }
       }
     } else {

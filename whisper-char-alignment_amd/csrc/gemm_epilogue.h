@@ -108,16 +108,19 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
       if (full_n && ((reinterpret_cast<uintptr_t>(cp + fg * 8) & 15) == 0)) {
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          half8 o;
+          half8 o, ol;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[hh * 8 + j];
-          *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
-          if (OUT_MODE == 4) {  // lo halves, c_lo elements further (a multiple of 8: same alignment)
-            half8 ol;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) ol[j] = (half_t)(v[hh * 8 + j] - (float)o[j]);
-            *reinterpret_cast<half8*>(cp + a.c_lo + hh * 32 + fg * 8) = ol;
+          for (int j = 0; j < 8; ++j) {
+            if (OUT_MODE == 4) {
+              const HalfPair pr = split_pair(v[hh * 8 + j]);
+              o[j] = pr.hi;
+              ol[j] = pr.lo;
+            } else {
+              o[j] = (half_t)v[hh * 8 + j];
+            }
           }
+          *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
+          if (OUT_MODE == 4) *reinterpret_cast<half8*>(cp + a.c_lo + hh * 32 + fg * 8) = ol;  // lo halves (c_lo % 8 == 0: same alignment)
         }
       } else {
 #pragma unroll
@@ -125,9 +128,13 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (nbase + col[nt] + r < a.N) {
-              const half_t hv = (half_t)v[nt * 4 + r];
-              cp[col[nt] + r] = hv;
-              if (OUT_MODE == 4) cp[a.c_lo + col[nt] + r] = (half_t)(v[nt * 4 + r] - (float)hv);
+              if (OUT_MODE == 4) {
+                const HalfPair pr = split_pair(v[nt * 4 + r]);
+                cp[col[nt] + r] = pr.hi;
+                cp[a.c_lo + col[nt] + r] = pr.lo;
+              } else {
+                cp[col[nt] + r] = (half_t)v[nt * 4 + r];
+              }
             }
       }
     } else {

@@ -145,9 +145,13 @@ __global__ __launch_bounds__(256) void logmel_finalize_kernel(LogMelArgs a) {
       if (t < NFRAMES) {
         const float v = (t < na) ? sc[(long)m * NFRAMES + t] : -10.0f;
         const float y = (fmaxf(v, floorv) + 4.0f) * 0.25f;
-        const half_t hv = (half_t)y;
-        mt[(long)(t + 1) * a.n_mels_pad + m] = hv;
-        if (a.tm_lo) mt[(long)(t + 1) * a.n_mels_pad + a.tm_lo + m] = (half_t)(y - (float)hv);
+        if (a.tm_lo) {
+          const HalfPair pr = split_pair(y);
+          mt[(long)(t + 1) * a.n_mels_pad + m] = pr.hi;
+          mt[(long)(t + 1) * a.n_mels_pad + a.tm_lo + m] = pr.lo;
+        } else {
+          mt[(long)(t + 1) * a.n_mels_pad + m] = (half_t)y;
+        }
       }
     }
   }

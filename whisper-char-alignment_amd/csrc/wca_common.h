@@ -83,10 +83,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ float gelu_erf_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // x -> (hi, lo) with hi = f16(x), lo = f16(x - hi): x = hi + lo up to 2^-22 |x| (lo is exact in f32; it rounds to f16 with
-// 11 more bits, or to the f16 subnormal grid, 6e-8 absolute, for |x| below ~0.1)
-__device__ __forceinline__ void split_f16(float x, half_t& hi, half_t& lo) {
-  hi = (half_t)x;
-  lo = (half_t)(x - (float)hi);
+// 11 more bits, or to the f16 subnormal grid, 6e-8 absolute, for |x| below ~0.1). The value is PINNED in a register first:
+// with -ffp-contract=fast (the HIP default) hipcc otherwise folds the multiply that produced x into ONE of the two conversions
+// (v_fma_mixlo_f16 rounds the exact product once, the other use rounds the fp32 value), and at an exact f16 tie the stored hi and
+// the hi under the subtraction are different neighbours -- lo then has the wrong sign (measured: one element in ~8000, error 1 ulp
+// of hi).
+struct HalfPair {
+  half_t hi, lo;
+};
+__device__ __forceinline__ HalfPair split_pair(float x) {
+  asm volatile("" : "+v"(x));
+  HalfPair r;
+  r.hi = (half_t)x;
+  r.lo = (half_t)(x - (float)r.hi);
+  return r;
 }
 
 // Bijective XCD-aware remap of a linear workgroup id: blocks that share an XCD
