@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=32, help="utterances timed by the CPU baseline (after 1 warm-up)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = every core this process may use, measured; recorded in the line)")
     ap.add_argument("--aligned-utts", type=int, default=8, help="utterances of the second parity leg (alignment-like planted checkpoint: "
                     "synthetic.aligned_state_dict), aligned by the CPU oracle and by the GPU path in a full batch; 0 = skip")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
@@ -71,6 +72,7 @@ def parse():
     ap.add_argument("--precision", choices=("f16", "split"), default="f16",
                     help="f16: operands rounded to f16 once (fastest; the headline). split: reference precision -- every operand as an f16 "
                          "(hi, lo) pair against the exact f16 weights, three-pass attention (wca_set_precision); same contract line")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the reference-precision (split) throughput + parity leg that follows the f16 run")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collation rehearsal without a GPU: every rank fabricates its "
                     "shard's results instead of aligning (CPU tests of the --gpus N self-launch with WCA_DIST_BACKEND=gloo)")
     return ap.parse_args()
@@ -181,10 +183,9 @@ def build_inputs(syn, tok_mod, retok, args, n_batches, rank, world, device):
     return tok, batches
 
 
-def host_cores():
-    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands each job a
-    share of a large host -- 16 cores per GPU on this pool, the default cap; WCA_CPU_THREADS overrides -- and over-subscribing
-    the share stalls the baseline)."""
+def host_cores(override=0):
+    """Cores this process may use, as MEASURED: the affinity mask capped by the cgroup CPU quota. `override` (--cpu-threads, or
+    WCA_CPU_THREADS) replaces it and is recorded in the line. Returns (threads used, measured cores, override or None)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -193,7 +194,8 @@ def host_cores():
             n = min(n, max(1, int(int(quota) / int(period))))
     except (OSError, ValueError):
         pass
-    return max(1, min(n, int(os.environ.get("WCA_CPU_THREADS", "16"))))
+    ov = int(override) if override else int(os.environ.get("WCA_CPU_THREADS", "0"))
+    return (max(1, ov) if ov > 0 else max(1, n)), max(1, n), (ov if ov > 0 else None)
 
 
 def cpu_model():
@@ -210,7 +212,7 @@ def cpu_model():
 def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
     """Oracle (CPU restatement of the reference pipeline, kind 'port') on a bounded sample, every host core."""
     from oracle import timing_ref, whisper_ref, tokenizer_ref
-    cores = host_cores()
+    cores, cores_measured, cores_override = host_cores(args.cpu_threads)
     torch.set_num_threads(cores)
     tok = tokenizer_ref.CharTokenizer()
     ref = whisper_ref.WhisperRef(sd, dims)
@@ -236,7 +238,8 @@ def cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times):
         if u > 0:
             times.append(dt)
     per = float(np.mean(times))
-    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "host_cpu_count": os.cpu_count(), "cpu": cpu_model(), "kind": "port",
+    return {"value": 1.0 / per, "unit": "utterances/s", "cores": cores, "cores_measured": cores_measured, "cores_measured_as": "min(sched_getaffinity, cgroup cpu.max quota)",
+            "cpu_threads_override": cores_override, "host_cpu_count": os.cpu_count(), "cpu": cpu_model(), "kind": "port",
             "sample": "%d utterances (after 1 warm-up) of the same synthetic workload, batch 1 serial like infer_ali.py:48,57, "
                       "PyTorch-CPU fp32 forward (torch.set_num_threads(%d)) + oracle post-processing, %.2f s/utt" % (len(times), cores, per)}
 
@@ -414,7 +417,22 @@ def measured_traffic(args, dims, site):
     return None, None
 
 
+def executed_tflop_per_utt(dims, args):
+    """Algorithmic TFLOP (2 x MAC, SURVEY.md 8d formulas) of what the fused alignment path executes for one utterance."""
+    S, d, ff, L = 1500, dims.n_audio_state, 4 * dims.n_audio_state, dims.n_audio_layer
+    dt, Ld, V = dims.n_text_state, dims.n_text_layer, dims.n_vocab
+    n = args.chars + 5
+    enc = 2 * dims.n_mels * 3 * d * 3000 + 2 * d * 3 * d * S + L * (8 * S * d * d + 4 * S * S * d + 4 * S * d * ff)
+    per_dec = 8 * n * dt * dt + 4 * n * n * dt + 4 * n * dt * dt + 4 * S * dt * dt + 4 * n * S * dt + 4 * n * dt * 4 * dt
+    dec = Ld * per_dec
+    # elided: last layer's cross value projection (2 S dt^2), its P.V (2 n S dt), cross out-projection (2 n dt^2), MLP (16 n dt^2 / 2 ...)
+    elided = 2 * S * dt * dt + 2 * n * S * dt + 2 * n * dt * dt + 4 * n * dt * 4 * dt
+    return (enc + dec - elided) / 1e12   # (the vocabulary projection, 2 n dt V, is not run at all on this path)
+
+
 def git_head():
+    if os.environ.get("WCA_COMMIT"):   # the GPU box's copy has no .git: the launching command passes the hash in
+        return os.environ["WCA_COMMIT"]
     try:
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
     except (OSError, subprocess.SubprocessError):
@@ -491,78 +509,91 @@ def main():
             if collect is not None:
                 collect[(i * args.batch + j) * world + rank] = (st, en)
 
-    for i in range(args.warmup):
-        enqueue(i)
-        finish(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    model.set_profiling(True)
-    results = {}
-    t0 = time.perf_counter()
-    # software pipeline of depth 2: the host tail of step i-1 runs while the GPU executes step i
     SITES = ("qkv", "attention", "out_proj", "fc1", "fc2", "ln1", "ln2")
-    site_acc = {s: [0, 0.0, 0.0, 0.0] for s in SITES}   # launches, summed ms, flops / launch, bytes / launch
-    sampled_steps = 0
 
-    def sample_sites():
-        # HIP-event pairs around every launch of every encoder kernel of the batch enqueued last (recorded on the engine's
-        # stream by each enqueue); reading them waits for that batch, so only every 8th step is sampled (a sampled step delays
-        # the next enqueue by the read: ~0.2 % of the timed region)
-        nonlocal sampled_steps
-        for s_ in SITES:
-            n, ms, fl, by = model.kernel_ms(s_)
-            site_acc[s_][0] += n
-            site_acc[s_][1] += ms
-            site_acc[s_][2], site_acc[s_][3] = fl, by
-        sampled_steps += 1
+    def timed_region(steps, warmup):
+        """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides, the product's
+        collation inside the bracket, max over ranks. Returns (elapsed s, per-site HIP-event sums, sampled steps, stage ms, #collated)."""
+        for i in range(warmup):
+            enqueue(i)
+            finish(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        model.set_profiling(True)
+        results = {}
+        site_acc = {s_: [0, 0.0, 0.0, 0.0] for s_ in SITES}   # launches, summed ms, flops / launch, bytes / launch
+        sampled = 0
 
-    for i in range(args.steps):
-        enqueue(i)
-        if i > 0:
-            finish(i - 1, results)
-        if i % 8 == 7 and i + 1 < args.steps:
-            sample_sites()
-    finish(args.steps - 1, results)
-    # collate exactly like infer_ali.py does: packed (index, n, starts, ends) records through one size gather + one
-    # all-gather, and the 3-counter all-reduce (the only collectives on the path; no-ops for one rank)
-    coll_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
-    merged = shard.allgather_results(results, device=coll_dev)
-    counters = shard.allreduce_counters(len(results), len(results), len(results), device=coll_dev)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    # HIP-event pairs around every launch of every encoder kernel were recorded on the engine stream during the
-    # last timed step (they are re-recorded by each enqueue)
-    sample_sites()   # the last step (complete: its results were fetched)
-    sites = {s_: tuple(site_acc[s_]) for s_ in SITES}
-    stage_ms = model.last_stage_ms() if args.stages else None
-    model.set_profiling(False)
-    assert len(merged) == world * args.steps * args.batch and counters[0] == len(merged)
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        def sample_sites():
+            # HIP-event pairs around every launch of every encoder kernel of the batch enqueued last (recorded on the engine's
+            # stream by each enqueue); reading them waits for that batch, so only every 8th step is sampled (a sampled step delays
+            # the next enqueue by the read: ~0.2 % of the timed region)
+            nonlocal sampled
+            for s_ in SITES:
+                n, ms, fl, by = model.kernel_ms(s_)
+                site_acc[s_][0] += n
+                site_acc[s_][1] += ms
+                site_acc[s_][2], site_acc[s_][3] = fl, by
+            sampled += 1
 
-    if rank == 0:
-        total_utts = world * args.batch * args.steps
-        kernels = {}
-        if args.precision == "split":
-            for k_, v_ in list(SITE_SYMBOL.items()):
-                SITE_SYMBOL[k_] = v_.replace("attn32_kernel<false>", "attn_split_kernel<false, false>").replace("gemm256p_f16_kernel<0,", "gemm256p_f16_kernel<4,") \
+        t0 = time.perf_counter()
+        # software pipeline of depth 2: the host tail of step i-1 runs while the GPU executes step i
+        for i in range(steps):
+            enqueue(i)
+            if i > 0:
+                finish(i - 1, results)
+            if i % 8 == 7 and i + 1 < steps:
+                sample_sites()
+        finish(steps - 1, results)
+        # collate exactly like infer_ali.py does: packed (index, n, starts, ends) records through one size gather + one
+        # all-gather, and the 3-counter all-reduce (the only collectives on the path; no-ops for one rank)
+        coll_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
+        merged = shard.allgather_results(results, device=coll_dev)
+        counters = shard.allreduce_counters(len(results), len(results), len(results), device=coll_dev)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        sample_sites()   # the last step (complete: its results were fetched)
+        stage_ms = model.last_stage_ms() if args.stages else None
+        model.set_profiling(False)
+        assert len(merged) == world * steps * args.batch and counters[0] == len(merged)
+        if dist is not None:
+            tmax = torch.tensor([elapsed], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return elapsed, {s_: tuple(site_acc[s_]) for s_ in SITES}, sampled, stage_ms, len(merged)
+
+    def kernel_table(sites, precision):
+        sym = dict(SITE_SYMBOL)
+        if precision == "split":
+            for k_, v_ in list(sym.items()):
+                sym[k_] = v_.replace("attn32_kernel<false>", "attn_split_kernel<false, false>").replace("gemm256p_f16_kernel<0,", "gemm256p_f16_kernel<4,") \
                     + " [split mode: K doubled]"
-        for s, (n, ms, fl, by) in sites.items():
+        kernels = {}
+        for s_, (n, ms, fl, by) in sites.items():
             if n == 0:
                 continue  # e.g. the LayerNorm sites when the LayerNorms run inside the GEMM epilogues
             avg = ms / max(n, 1)
-            mfma = s not in ("ln1", "ln2")
+            mfma = s_ not in ("ln1", "ln2")
             ach = (fl if mfma else by) / (avg * 1e-3) / (1e12 if mfma else 1e9) if avg > 0 else 0.0
-            kernels[s] = {"symbol": SITE_SYMBOL[s], "launches": n, "avg_launch_ms": avg, "total_ms": ms, "bound": "mfma" if mfma else "hbm",
-                          "achieved": ach, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / (MFMA_F16_DENSE_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)}
-        dom = max(kernels, key=lambda s: kernels[s]["total_ms"])
-        traffic, traffic_src = measured_traffic(args, dims, dom)
+            kernels[s_] = {"symbol": sym[s_], "launches": n, "avg_launch_ms": avg, "total_ms": ms, "bound": "mfma" if mfma else "hbm",
+                           "achieved": ach, "unit": "TFLOP/s" if mfma else "GB/s", "frac": ach / (MFMA_F16_DENSE_PEAK_TFLOPS if mfma else HBM_PEAK_GBS)}
+        return kernels, sym
+
+    elapsed, sites, sampled_steps, stage_ms, n_collated = timed_region(args.steps, args.warmup)
+
+    if rank == 0:
+        total_utts = world * args.batch * args.steps
+        kernels, sym = kernel_table(sites, args.precision)
+        dom = max(kernels, key=lambda s_: kernels[s_]["total_ms"])
+        traffic, traffic_src = measured_traffic(args, dims, dom) if args.precision == "f16" else (None, None)
         d = dims.n_audio_state
+        # FLOPs the timed path EXECUTES per utterance: SURVEY 8(d)'s 1.356 T minus what the fused path elides because nobody reads it
+        # (the last decoder layer stops after its cross-attention capture: its value projection, P.V, cross out-projection and MLP,
+        # the final LayerNorm and the vocabulary projection)
+        executed_tflop = executed_tflop_per_utt(dims, args)
         out = {
             "metric": METRIC, "value": total_utts / elapsed, "unit": "utterances/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -571,7 +602,8 @@ def main():
             "config": {"workload": "configs[1] shape (TIMIT-like): whisper-%s dims, seeded random weights (peaky cross-attention), %.0f s @ 16 kHz "
                                    "gated noise, %d-char teacher text, char align, aggr=topk topk=%d medfilt_width=%d; %d distinct utterances per GPU"
                                    % (args.model, args.seconds, args.chars, args.topk, args.medfilt_width, len(batches) * args.batch),
-                       "precision": args.precision + (" (operands rounded to f16 once, fp32 accumulate)" if args.precision == "f16" else
+                       "precision": args.precision + (" (operands rounded to f16 once, fp32 accumulate; the reference-precision mode of the same run is "
+                                                      "under `reference_precision`)" if args.precision == "f16" else
                                                       " (wca_set_precision SPLIT: K-doubled GEMMs on [hi | lo] x [W | W], three-pass attention; "
                                                       "achieved / frac count ALGORITHMIC flops, the MFMA pipe executes 2x (GEMM) / 3x (attention) of them)"),
                        "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world,
@@ -579,9 +611,12 @@ def main():
                        "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region",
                        "dist_ranks": dist.get_world_size() if dist is not None else 1,
                        "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
-                       "collated_utterances": len(merged), "collective_calls": dict(shard.COLLECTIVE_CALLS),
-                       "pipeline_tflops": total_utts * 1.356 / elapsed, "commit": git_head()},
-            "roofline": {"bound": "mfma", "kernel": "%s, M=%d d=%d" % (SITE_SYMBOL[dom], args.batch * 1500, d),
+                       "collated_utterances": n_collated, "collective_calls": dict(shard.COLLECTIVE_CALLS),
+                       "pipeline_tflops": total_utts * executed_tflop / elapsed,
+                       "pipeline_tflops_note": "executed algorithmic TFLOP per utterance %.4f (SURVEY 8d total 1.356 minus the elided tail of the last "
+                                               "decoder layer and the unused logits)" % executed_tflop,
+                       "commit": git_head()},
+            "roofline": {"bound": "mfma", "kernel": "%s, M=%d d=%d" % (sym[dom], args.batch * 1500, d),
                          "selected_as": "largest total time of the encoder kernel sites over the sampled steps of the timed region (every 8th step + the last: %d steps)" % sampled_steps,
                          "achieved": kernels[dom]["achieved"], "peak": MFMA_F16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": kernels[dom]["frac"], "traffic": traffic, "traffic_source": traffic_src,
@@ -593,12 +628,29 @@ def main():
             names = ["logmel", "encoder", "cross_kv", "decoder", "head_stats", "topk_aggregate", "dtw", "total"]
             print("stage ms/step (last step): " + ", ".join("%s=%.3f" % (n, v) for n, v in zip(names, stage_ms)), file=sys.stderr)
             print("encoder kernel sites (%d sampled steps of the timed region): " % sampled_steps + ", ".join("%s=%.3f ms x%d (%.0f %s)" % (
-                s, k["avg_launch_ms"], k["launches"], k["achieved"], k["unit"]) for s, k in kernels.items()), file=sys.stderr)
+                s_, k["avg_launch_ms"], k["launches"], k["achieved"], k["unit"]) for s_, k in kernels.items()), file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             oracle_times = []
             out["cpu_baseline"] = cpu_baseline(args, sd, dims, syn, audio_mod, oracle_times)
             # same utterances through the GPU path at the timed configuration, checked against the oracle's word times
             out["cpu_baseline"]["parity"] = parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device)
+            if args.precision == "f16" and not args.no_split_leg:
+                # the SAME engine switched to the reference-precision mode: its throughput (a shorter timed region of the same
+                # shape) and its parity against the SAME oracle results
+                model.set_precision("split")
+                steps2 = max(8, args.steps // 4)
+                el2, sites2, _n2, _st2, _c2 = timed_region(steps2, 2)
+                k2, _sym2 = kernel_table(sites2, "split")
+                args.precision = "split"
+                par2 = parity_against_oracle(args, model, tok, opts, timing, retok, syn, oracle_times, device)
+                args.precision = "f16"
+                model.set_precision("f16")
+                out["reference_precision"] = {
+                    "mode": "wca_set_precision(WCA_PRECISION_SPLIT): every operand as an f16 (hi, lo) pair against the exact f16 weights "
+                            "(K-doubled GEMMs, three-pass attention, erff GELU, f64 log-mel DFT): the fp32 forward of timing.py:58 to fp32 summation noise",
+                    "value": args.batch * steps2 / el2, "unit": "utterances/s", "steps": steps2, "ms_per_step": 1e3 * el2 / steps2,
+                    "kernels": {s_: {"avg_launch_ms": v["avg_launch_ms"], "achieved_algorithmic": v["achieved"], "unit": v["unit"]} for s_, v in k2.items()},
+                    "parity": par2}
             if args.aligned_utts > 0:
                 out["cpu_baseline"]["parity_alignment_like"] = parity_alignment_like(args, wca, dims, syn, audio_mod, tok_mod, retok, timing, device)
         else:

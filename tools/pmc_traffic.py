@@ -55,7 +55,8 @@ def main():
         N = K = None
         algo = (M * 3 * d + M * d) * 2
     import subprocess
-    head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    # the GPU box has no .git: the collecting command passes the hash in (WCA_COMMIT=$(git rev-parse --short HEAD) expanded where the repo is)
+    head = os.environ.get("WCA_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     res = {
         "site": site, "kernel": needle, "batch": batch, "model": model, "M": M, "N": N, "K": K, "launches_averaged": n, "commit": head,
         "FETCH_SIZE_raw_bytes": fetch_b, "FETCH_SIZE_corrected_x2_bytes": 2.0 * fetch_b, "WRITE_SIZE_bytes": write_b,
