@@ -40,9 +40,9 @@ HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 SITE_SYMBOL = {
     "qkv": "gemm256p_f16_kernel<0, false, 1, false> (encoder QKV projection, N=3d K=d)",
     "attention": "attn32_kernel<false> (encoder self-attention 1500x1500, head_dim 64)",
-    "out_proj": "gemm256p_f16_kernel<2, false, 1, false> (encoder attention out-projection + f32 residual read-modify-write; N=d K=d; with --fuse-ln the <3, ...> kernel incl. mlp_ln)",
+    "out_proj": "gemm256p_f16_kernel<3, false, 1, false> (encoder attention out-projection + f32 residual read-modify-write + mlp_ln in the epilogue; N=d K=d; with --no-fuse-ln the <2, ...> kernel, mlp_ln a separate launch)",
     "fc1": "gemm256p_f16_kernel<0, true, 1, false> (encoder MLP fc1 + GELU, N=4d K=d)",
-    "fc2": "gemm256p_f16_kernel<2, false, 4, false> (encoder MLP fc2 + f32 residual read-modify-write; N=d K=4d; with --fuse-ln the <3, ...> kernel incl. the next attn_ln)",
+    "fc2": "gemm256p_f16_kernel<3, false, 4, false> (encoder MLP fc2 + f32 residual read-modify-write + the next attn_ln / ln_post in the epilogue; N=d K=4d; with --no-fuse-ln the <2, ...> kernel)",
     "ln1": "layernorm_f16_v4_kernel (attn_ln launches + ln_post)",
     "ln2": "layernorm_f16_v4_kernel (mlp_ln launches)",
 }
@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--aligned-utts", type=int, default=8, help="utterances of the second parity leg (alignment-like planted checkpoint: "
                     "synthetic.aligned_state_dict), aligned by the CPU oracle and by the GPU path in a full batch; 0 = skip")
     ap.add_argument("--stages", action="store_true", help="print a per-stage HIP-event breakdown to stderr")
-    ap.add_argument("--fuse-ln", action="store_true", help="LayerNorms inside the residual GEMMs' epilogues instead of separate launches (A/B)")
+    ap.add_argument("--no-fuse-ln", action="store_true", help="LayerNorms as separate launches instead of inside the residual GEMMs' epilogues (A/B)")
     ap.add_argument("--dec-unfused", action="store_true", help="decoder GEMMs on <= 256 rows as separate LayerNorm / GEMM launches (A/B of the few-row kernel; matters at small batch)")
     ap.add_argument("--no-overlap", action="store_true", help="phase 2 on the same stream as phase 1 (clean per-kernel rocprofv3 averages)")
     ap.add_argument("--precision", choices=("f16", "split"), default="f16",
@@ -489,7 +489,7 @@ def main():
     model.set_precision(args.precision)
     if args.no_overlap:
         model.set_overlap(False)
-    model.set_fuse_ln(bool(args.fuse_ln))
+    model.set_fuse_ln(not args.no_fuse_ln)
     if args.dec_unfused:
         model.set_decode_mode(False, 1)
     tok, batches = build_inputs(syn, tok_mod, retok, args, max(2, args.distinct_batches), rank, world, device)
@@ -567,6 +567,9 @@ def main():
 
     def kernel_table(sites, precision):
         sym = dict(SITE_SYMBOL)
+        if precision == "split" or args.no_fuse_ln:   # separate LayerNorm launches: the residual GEMMs are the <2, ...> kernels
+            for k_ in ("out_proj", "fc2"):
+                sym[k_] = sym[k_].replace("gemm256p_f16_kernel<3,", "gemm256p_f16_kernel<2,")
         if precision == "split":
             for k_, v_ in list(sym.items()):
                 sym[k_] = v_.replace("attn32_kernel<false>", "attn_split_kernel<false, false>").replace("gemm256p_f16_kernel<0,", "gemm256p_f16_kernel<4,") \

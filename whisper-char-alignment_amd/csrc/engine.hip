@@ -213,7 +213,8 @@ struct wca_engine {
     int k1pad = 0;           // padded K of the split conv1 GEMM: windows of 3 frames x [hi(C) | lo(C)]
     std::vector<LayerW> enc, dec;  // only the half_t* members are used
   } sw;
-  bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln)
+  bool fuse_ln = true;       // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln; default on,
+                             // never in split mode)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
