@@ -402,7 +402,7 @@ def measured_traffic(args, dims, site):
     """HBM-side bytes per launch of the dominant kernel from the separate rocprofv3 --pmc passes recorded under
     profiles/ (tools/pmc_traffic.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, + WRITE_SIZE).
     Quoted only when that file was collected on this configuration and this kernel; carries its provenance."""
-    files = {"fc1": "r02_dominant_kernel_traffic.json", "fc2": "r02_traffic_fc2.json", "qkv": "r02_traffic_qkv.json", "out_proj": "r02_traffic_out_proj.json"}
+    files = {"fc1": "r03_traffic_fc1.json", "fc2": "r03_traffic_fc2.json", "qkv": "r03_traffic_qkv.json", "out_proj": "r03_traffic_out_proj.json"}
     name = files.get(site)
     if name is None:
         return None, None

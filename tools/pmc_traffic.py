@@ -29,9 +29,9 @@ def per_launch(d, counter, needle):
 
 SITES = {  # site -> (kernel-name substring, lambda(M, d) -> (N, K), read-modify-write f32 residual?)
     "qkv": ("gemm256p_f16_kernel<0, false, 1, false>", lambda d: (3 * d, d), False),
-    "out_proj": ("gemm256p_f16_kernel<2, false, 1, false>", lambda d: (d, d), True),
+    "out_proj": ("gemm256p_f16_kernel<3, false, 1, false>", lambda d: (d, d), True),   # round 3: LayerNorm fused (default)
     "fc1": ("gemm256p_f16_kernel<0, true, 1, false>", lambda d: (4 * d, d), False),
-    "fc2": ("gemm256p_f16_kernel<2, false, 4, false>", lambda d: (d, 4 * d), True),
+    "fc2": ("gemm256p_f16_kernel<3, false, 4, false>", lambda d: (d, 4 * d), True),
     "attention": ("attn32_kernel<false>", None, False),
 }
 
@@ -50,7 +50,7 @@ def main():
     M = batch * 1500
     if nk is not None:
         N, K = nk(d)
-        algo = (M * K + N * K) * 2 + N * 4 + (M * N * 8 if rmw else M * N * 2)
+        algo = (M * K + N * K) * 2 + N * 4 + (M * N * 10 if rmw else M * N * 2)   # rmw: f32 residual read + write, + the fused LayerNorm's f16 output
     else:
         N = K = None
         algo = (M * 3 * d + M * d) * 2
