@@ -67,6 +67,27 @@ def test_infer_ali_and_eval_ali(corpus, capsys):
     assert abs(r["precision"] - res["precision"]) < 1e-9 and abs(r["recall"] - res["recall"]) < 1e-9
 
 
+def test_infer_ali_precision_split(corpus):
+    """--forward_precision split (the reference-precision mode) through the CLI: same schemas, and on this tiny random model the word
+    times of the two modes agree to within a few frames (they differ by operand rounding only)."""
+    root, scp = corpus
+    infer = _m("infer_ali")
+    import joblib
+    preds = {}
+    for mode in ("f16", "split"):
+        out = root / ("out_" + mode)
+        args = infer.parse_args(["--model", "tiny", "--random_init", "--dataset", "TIMIT", "--scp", str(scp), "--output_dir", str(out),
+                                 "--aggr", "topk", "--topk", "5", "--aligned_unit_type", "char", "--medfilt_width", "3", "--batch_size", "2",
+                                 "--save_prediction", "--teacher", "text", "--forward_precision", mode])
+        infer.infer_dataset(args)
+        res = json.load(open(glob.glob(str(out / "*.json"))[0]))
+        assert res["forward_precision"] == mode and 0.0 <= res["precision"] <= 1.0   # (`precision` = the P of P/R/F1, reference schema)
+        preds[mode] = joblib.load(glob.glob(str(out / "*-predictions.pkl"))[0])
+    assert sorted(preds["split"]) == sorted(preds["f16"]) == [0, 1, 2, 3, 4]
+    same = sum(int(np.array_equal(preds["f16"][n]["ends_hat"], preds["split"][n]["ends_hat"])) for n in preds["f16"])
+    assert same >= 3, same
+
+
 def test_infer_ali_teacher_asr(corpus, fake_vocab, capsys):
     """The reference's own flow (infer_ali.py:60-68): greedy ASR pre-pass -> remove_punctuation -> char tokens -> alignment
     re-using the encoder state. Random weights give a meaningless hypothesis; this checks the plumbing end to end
