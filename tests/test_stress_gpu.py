@@ -8,7 +8,7 @@ configs[4]  probe_oracle.py full L x H head sweep, whisper-large-v3 (/root/refer
             640 heads' maps resident (1.72 GB at n = 448, F = 1500), one DTW per head in ONE launch.
 
 Integer results are held to the bit-exact bar: every DTW path must equal the oracle's dtw_cpu restatement run on the
-SAME (device-computed) matrix. Timings go to gpurun_out/r02_stress.txt (copied to profiles/)."""
+SAME (device-computed) matrix. Timings go to gpurun_out/r03_stress.txt (copied to profiles/)."""
 import importlib
 import os
 import time
@@ -30,7 +30,7 @@ def _log(line):
     print(line, flush=True)
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
-        with open(os.path.join(d, "r02_stress.txt"), "a") as f:
+        with open(os.path.join(d, "r03_stress.txt"), "a") as f:
             f.write(line + "\n")
 
 
@@ -98,6 +98,46 @@ def test_config3_large_v2_char_max_sizes(wca, large_v2, aggr, topk):
         if aggr == "topk":
             assert list(sel[b]) == [l * 20 + h for _, (l, h), _ in scores]
     _log("configs[3] char   aggr=%-4s wca_force_align (640 heads x 448 x 1500 scores/select/aggregate/DTW/D2H): %.1f ms" % (aggr, t_fa * 1e3))
+
+
+def test_config3_large_v2_reference_precision_mode(wca, large_v2):
+    """configs[3] at full size in the reference-precision (split) mode: d = 1280 (20 heads, K doubled to 2560 / 10240), n = 448,
+    F = 1500. Fused batch path == step-by-step API == oracle DTW of the device matrix (bit-exact), and the softmaxed maps agree
+    with the default mode's to its f16 operand noise (the two modes run different kernels end to end)."""
+    syn, tk, rt, tm, audio = _m("synthetic"), _m("tokenizer"), _m("retokenize"), _m("timing"), _m("audio")
+    dims, model = large_v2
+    tok = tk.get_tokenizer(True, language="English")
+    B = 2
+    pcm = np.stack([syn.synth_audio(900 + u, 480000) for u in range(B)])
+    tts = [rt.encode(syn.synth_text(900 + u, 443), tok, "char") for u in range(B)]
+    toks = np.array([[*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot] for tt in tts], dtype=np.int64)
+    opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=7)
+    pcm_d, tok_d = torch.from_numpy(pcm).cuda(), torch.from_numpy(toks).cuda()
+    mels = torch.stack([audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm[b])), 80, model=model) for b in range(B)]).cuda()
+    w16, _ = model.get_attentions(mels[:1], tok_d[:1], [1500], 7, 1.0, want_logits=False)
+    w16 = w16[0, -1].clone()          # last decoder layer's 20 heads in the default mode
+    model.set_precision("split")
+    try:
+        model.align_batch(pcm_d, [480000] * B, tok_d, [448] * B, [1500] * B, opts)  # warm-up (buffer growth)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        jump, sel = model.align_batch(pcm_d, [480000] * B, tok_d, [448] * B, [1500] * B, opts)
+        dt = time.time() - t1
+        _log("configs[3] char   aggr=topk B=%d n=448 F=1500 fused align_batch, SPLIT mode: %.1f ms per batch (%.2f utt/s)" % (B, dt * 1e3, B / dt))
+        mels_s = torch.stack([audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm[b])), 80, model=model) for b in range(B)]).cuda()
+        w_all, _ = model.get_attentions(mels_s, tok_d, [1500] * B, 7, 1.0, want_logits=False)
+        assert (w_all[0, -1] - w16).abs().max().item() < 2e-2
+        for b in range(B):
+            w = w_all[b]
+            words, st, en, matrix, scores = tm.force_align(w, tts[b], tok, "char", "topk", topk=10)
+            del w
+            ti, tj, rst, ren = _oracle_times(matrix, tts[b], tok, "char", rt.split_tokens_on_spaces)
+            assert np.array_equal(st, rst) and np.array_equal(en, ren)
+            jm = np.pad(np.diff(ti), (1, 0), constant_values=1).astype(bool)
+            assert np.array_equal(jump[b, :444], tj[jm])
+            assert list(sel[b]) == [l * 20 + h for _, (l, h), _ in scores]
+    finally:
+        model.set_precision("f16")
 
 
 def test_config3_large_v2_subword_1500_frames(wca, large_v2, fake_vocab):
