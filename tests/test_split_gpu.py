@@ -217,7 +217,7 @@ def test_split_forward_vs_oracle_small_dims(wca):
     del model
 
 
-OFFENDER_IDS = [10007, 10030, 10035, 10076, 10113, 10120]   # outside one frame in the f16-operand mode (profiles/r02_parity_leg_128utt.json)
+OFFENDER_IDS = [10007, 10030, 10035, 10076, 10113, 10120]   # outside one frame in round 2's f16-operand mode (profiles/r02_parity_leg_128utt.json)
 
 
 def test_split_mode_closes_the_headline_parity_gap(wca):
@@ -227,8 +227,13 @@ def test_split_mode_closes_the_headline_parity_gap(wca):
       * every word boundary within one 20 ms frame -- except where the ORACLE's own k-th / (k+1)-th selection scores are closer
         than the measured score deviation (such a tie is decided by fp32 summation order in any implementation);
       * selection scores and aggregated matrix of the step-by-step API within 1e-5 / 2e-5 relative of the oracle's.
-    The same batch in the default mode is run for contrast (its offenders are printed, not asserted)."""
+    The same batch in the default mode is run for contrast: its offenders are printed, and each must lie outside the oracle-defined
+    acceptance set (which utterances the f16 mode misses changes with every last-bit change of its forward -- round 2: the six
+    above; with the LayerNorms in the GEMM epilogues: 10007 and 121)."""
+    import sys
     from oracle import timing_ref, whisper_ref, tokenizer_ref
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
     syn, tk, rt, tm, audio = _mods()
     dims = wca.dims_for("medium")
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
@@ -267,6 +272,12 @@ def test_split_mode_closes_the_headline_parity_gap(wca):
                 ident += int((np.asarray(st) == rst).sum() + (np.asarray(en) == ren).sum())
             if n_off:
                 store.append((uid, n_off, gap))
+                if jj is jump16:
+                    # a miss of the default mode must lie OUTSIDE the oracle-defined acceptance set of test_e2e_gpu.py (near-tied
+                    # selection or ill-conditioned path of the fp32 oracle itself): which utterances those are changes with every
+                    # last-bit change of the f16 forward, that they are of this kind must not
+                    in_set = gap > 2e-3 and not bench.oracle_is_ill_conditioned(rmatrix, list(tt), np.asarray(rst), np.asarray(ren), eps=3e-3, trials=32)
+                    assert not in_set, (uid, n_off, gap)
         if uid in OFFENDER_IDS:
             # step-by-step API in split mode on the utterance alone: scores and matrix against the oracle's
             w, _ = tm.get_attentions(mel.cuda(), torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
@@ -281,8 +292,6 @@ def test_split_mode_closes_the_headline_parity_gap(wca):
             print("utt %d: oracle 10th/11th score gap %.2e, max rel score deviation %.2e" % (uid, gap, dscore))
     print("split mode, medium B=64 fused: %d boundaries over %d utterances, identical %d, utterances with a boundary outside one frame: split %s | f16 %s; "
           "max rel |dscore| %.2e, rel |dmatrix| %.2e" % (total, len(ids), ident, off_split, off_f16, max_dscore, max_dmatrix))
-    # the default mode's misses are exactly the known ones (they are what this mode exists for); ids 100-131 are clean in both
-    assert {o[0] for o in off_f16} <= set(OFFENDER_IDS), off_f16
     assert max_dscore < 1e-5, max_dscore
     assert max_dmatrix < 2e-5, max_dmatrix
     # a miss is only acceptable where the oracle itself is tied at the selection cut below the measured score noise
