@@ -46,10 +46,23 @@ __device__ __forceinline__ float xor32_sumf(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ half4 tr_read4s(const half_t* p) {
-  s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((WCA_LDS s16x4*)(p));
-  return __builtin_bit_cast(half4, r);
+// Transposed LDS reads as inline asm with hand-counted lgkmcnt: hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of the first
+// ds_read_b64_tr_b16 BUILTIN of the loop (it cannot tell the transposed read from the LDS-DMA writes in flight), which drains the
+// next tile's K/V prefetch on every tile (on this kernel the prefetch has landed by then anyway: 2.13 vs 2.20 ms per encoder layer
+// at B = 64, within box variance -- kept because it removes the dependence on that timing). LDS operations return in issue order;
+// the wait names its destination registers so that no consumer can be scheduled above it.
+__device__ __forceinline__ unsigned lds_off_s(const void* p) { return (unsigned)(size_t)(const WCA_LDS char*)p; }
+template <int OFF>
+__device__ __forceinline__ half4 tr_read_asm(unsigned addr) {
+  half4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
 }
+#define WCA_S_LGKM_WAIT8(N, A, B, C, D, E, F, G, H)                                                                                  \
+  do {                                                                                                                               \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H)::"memory");  \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+  } while (0)
 
 template <bool CAUSAL, bool CAPTURE>
 __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
@@ -120,6 +133,17 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
   for (int s = 0; s < 2; ++s)
 #pragma unroll
     for (int d = 0; d < 4; ++d) ot[s][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // per-lane byte addresses of the V^T fragment reads in ring slot 0 (slot, hi / lo tile, k step and the second 16-key block are
+  // immediates): lane (fr = 4 qd + pd, fg) reads key 4 fg + qd (+ 32 k2, + 16), dims 16 dt + 4 pd .. +3; chunk c = 2 dt + (pd >> 1)
+  // sits at chunk position c ^ (key & 6), and key & 6 = 4 (fg & 1) | (qd & 2) for every one of this lane's keys
+  unsigned vaddr[4];
+  {
+    const int qd = fr >> 2, pd = fr & 3;
+    const int swz = (4 * (fg & 1)) | (qd & 2);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      vaddr[dt] = lds_off_s(lds) + 2u * (unsigned)((4 * fg + qd) * 64 + (((2 * dt + (pd >> 1)) ^ swz) << 3) + 4 * (pd & 1));
+  }
   float m_run[2] = {-INFINITY, -INFINITY};  // running row maximum of the RAW scores
   float l_part[2] = {0.f, 0.f};             // this lane's share of the row sum (its 16 keys per tile), reduced at the end
 
@@ -131,8 +155,6 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
     const half_t* Kh = lds + (kt & 1) * (4 * TILE);
     const half_t* Kl = Kh + TILE;
-    const half_t* Vh = Kl + TILE;
-    const half_t* Vl = Vh + TILE;
 
     // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r], three passes per 32-deep k step
     f32x4 st[2][4];
@@ -249,22 +271,37 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
     }
 
     // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr], k order matching the P fragments:
-    // j<4 -> key (2*k2)*16 + 4*fg + j, j>=4 -> key (2*k2+1)*16 + 4*fg + (j-4).
+    // j<4 -> key (2*k2)*16 + 4*fg + j, j>=4 -> key (2*k2+1)*16 + 4*fg + (j-4). The eight transposed reads of output block dt + 1
+    // (hi / lo x two k steps x two 16-key blocks) are in flight under the twelve MFMAs of block dt.
     {
-      const int qd = fr >> 2, pd = fr & 3;
+      const unsigned sb = (unsigned)(kt & 1) * (unsigned)(4 * TILE * sizeof(half_t));  // ring slot
+      constexpr int VH = 2 * TILE * (int)sizeof(half_t), VL = 3 * TILE * (int)sizeof(half_t);  // V hi / V lo tile inside a slot
+      constexpr int K2 = 32 * 64 * (int)sizeof(half_t), B16 = 16 * 64 * (int)sizeof(half_t);  // k step (32 keys), second 16-key block
+      half4 c_[8], n_[8];
+#define WCA_ISSUE_V(R, A)                                                                    \
+  do {                                                                                       \
+    R[0] = tr_read_asm<VH>(A);                                                               \
+    R[1] = tr_read_asm<VH + B16>(A);                                                         \
+    R[2] = tr_read_asm<VL>(A);                                                               \
+    R[3] = tr_read_asm<VL + B16>(A);                                                         \
+    R[4] = tr_read_asm<VH + K2>(A);                                                          \
+    R[5] = tr_read_asm<VH + K2 + B16>(A);                                                    \
+    R[6] = tr_read_asm<VL + K2>(A);                                                          \
+    R[7] = tr_read_asm<VL + K2 + B16>(A);                                                    \
+  } while (0)
+      WCA_ISSUE_V(c_, vaddr[0] + sb);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const int d = dt * 16 + 4 * pd;
-        const int c = d >> 3, w = d & 7;
+        if (dt < 3) {
+          WCA_ISSUE_V(n_, vaddr[dt + 1] + sb);
+          WCA_S_LGKM_WAIT8(8, c_[0], c_[1], c_[2], c_[3], c_[4], c_[5], c_[6], c_[7]);
+        } else {
+          WCA_S_LGKM_WAIT8(0, c_[0], c_[1], c_[2], c_[3], c_[4], c_[5], c_[6], c_[7]);
+        }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-          const int key0 = (2 * k2) * 16 + 4 * fg + qd;
-          const int key1 = key0 + 16;
-          const int o0 = key0 * 64 + ((c ^ (key0 & 6)) << 3) + w, o1 = key1 * 64 + ((c ^ (key1 & 6)) << 3) + w;
-          const half4 h0 = tr_read4s(Vh + o0), h1 = tr_read4s(Vh + o1);
-          const half4 l0 = tr_read4s(Vl + o0), l1 = tr_read4s(Vl + o1);
-          const half8 vh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-          const half8 vl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+          const half8 vh = __builtin_shufflevector(c_[4 * k2], c_[4 * k2 + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+          const half8 vl = __builtin_shufflevector(c_[4 * k2 + 2], c_[4 * k2 + 3], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int s = 0; s < 2; ++s) {
             ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph[s][k2], ot[s][dt], 0, 0, 0);
@@ -272,7 +309,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
             ot[s][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph[s][k2], ot[s][dt], 0, 0, 0);
           }
         }
+        if (dt < 3) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) c_[i] = n_[i];
+        }
       }
+#undef WCA_ISSUE_V
     }
   }
 
