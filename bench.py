@@ -72,6 +72,10 @@ def parse():
     ap.add_argument("--precision", choices=("f16", "split"), default="f16",
                     help="f16: operands rounded to f16 once (fastest; the headline). split: reference precision -- every operand as an f16 "
                          "(hi, lo) pair against the exact f16 weights, three-pass attention (wca_set_precision); same contract line")
+    ap.add_argument("--collate", choices=("torch", "abi"), default="torch",
+                    help="collation of the per-rank results: torch = torch.distributed collectives (backend nccl = RCCL; the default), "
+                         "abi = the C ABI's wca_allgather_results / wca_allreduce_counters (ncclAllGather from libwca.so; the communicator id "
+                         "travels over the torch.distributed store)")
     ap.add_argument("--no-split-leg", action="store_true", help="skip the reference-precision (split) throughput + parity leg that follows the f16 run")
     ap.add_argument("--dry-run", action="store_true", help="launcher / rendezvous / collation rehearsal without a GPU: every rank fabricates its "
                     "shard's results instead of aligning (CPU tests of the --gpus N self-launch with WCA_DIST_BACKEND=gloo)")
@@ -492,6 +496,13 @@ def main():
     model.set_fuse_ln(not args.no_fuse_ln)
     if args.dec_unfused:
         model.set_decode_mode(False, 1)
+    coll_engine = None
+    if args.collate == "abi" and dist is not None:
+        # one RCCL communicator per engine, created through the C ABI; only its 128-byte id uses the launcher's side channel
+        box = [wca.WhisperAMD.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        model.comm_init(box[0], rank, world)
+        coll_engine = model
     tok, batches = build_inputs(syn, tok_mod, retok, args, max(2, args.distinct_batches), rank, world, device)
     opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width,
                            qk_scale=1.0)
@@ -549,8 +560,8 @@ def main():
         # collate exactly like infer_ali.py does: packed (index, n, starts, ends) records through one size gather + one
         # all-gather, and the 3-counter all-reduce (the only collectives on the path; no-ops for one rank)
         coll_dev = device if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
-        merged = shard.allgather_results(results, device=coll_dev)
-        counters = shard.allreduce_counters(len(results), len(results), len(results), device=coll_dev)
+        merged = shard.allgather_results(results, device=coll_dev, engine=coll_engine)
+        counters = shard.allreduce_counters(len(results), len(results), len(results), device=coll_dev, engine=coll_engine)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -611,7 +622,9 @@ def main():
                                                       "achieved / frac count ALGORITHMIC flops, the MFMA pipe executes 2x (GEMM) / 3x (attention) of them)"),
                        "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world,
                        "streams": "one (no overlap)" if args.no_overlap else "phase 1 / phase 2 overlapped on two streams",
-                       "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region",
+                       "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region; "
+                                    + ("through the C ABI (wca_allgather_results / wca_allreduce_counters: ncclAllGather / ncclAllReduce from libwca.so)"
+                                       if coll_engine is not None else "torch.distributed collectives" if dist is not None else "one rank: passthrough"),
                        "dist_ranks": dist.get_world_size() if dist is not None else 1,
                        "dist_backend": (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if dist is not None else None,
                        "collated_utterances": n_collated, "collective_calls": dict(shard.COLLECTIVE_CALLS),

@@ -248,6 +248,26 @@ int wca_flac_info(const uint8_t* buf, int64_t nbytes, int32_t* sample_rate, int3
                   int64_t* total_samples);
 int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capacity_per_channel, int64_t* n_decoded);
 
+/* ---- collation of the per-rank results over RCCL -----------------------------------------------------
+ * The reference is single-process: infer_ali.py:53-56,118-132 accumulates every utterance's result in one dict and three
+ * counters. Here utterances shard over one process per GPU; at the end every rank hands its packed records
+ * ([utt_index:int32][n:int32][starts:f64 x n][ends:f64 x n] ..., shard.pack_results) to wca_allgather_results: an all-gather
+ * of the byte counts, then ONE all-gather of the buffers padded to the largest count (ncclAllGather over xGMI), and
+ * wca_allreduce_counters sums the evaluation counters. librccl is resolved at first use (dlopen; the copy already in the
+ * process if there is one). The 128-byte unique id is created on rank 0 and reaches the other ranks by the launcher's own
+ * side channel (a file, MPI, the torch.distributed store ...). One communicator per engine, on the engine's device and
+ * stream. The Python CLI / bench.py collate through torch.distributed (backend "nccl" = the same RCCL) by default;
+ * shard.allgather_results(..., engine=model) takes this path. */
+#define WCA_COMM_ID_BYTES 128
+int wca_comm_unique_id(uint8_t* id_out /* [WCA_COMM_ID_BYTES] */);
+int wca_comm_init(wca_engine* e, const uint8_t* id /* [WCA_COMM_ID_BYTES] */, int rank, int world);
+int wca_comm_destroy(wca_engine* e);
+/* gathered_host [world][capacity_per_rank]: rank r's sizes_host[r] bytes start at r * capacity_per_rank. WCA_ERR_TOO_LONG
+ * (on every rank alike) when some rank packed more than capacity_per_rank bytes; sizes_host is filled: retry with room. */
+int wca_allgather_results(wca_engine* e, const uint8_t* packed_host, int64_t n_bytes, uint8_t* gathered_host,
+                          int64_t capacity_per_rank, int64_t* sizes_host /* [world] */);
+int wca_allreduce_counters(wca_engine* e, int64_t* counters_host /* [n], summed in place */, int n);
+
 /* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
 /* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device. out_mode low byte: 0 f16 store, 1 f32 store,
  * 2 f32 accumulate, 4 f16 PAIR store (split mode: c_dev is f16 [M][2N], hi = f16(v) at column n, lo = f16(v - hi) at column

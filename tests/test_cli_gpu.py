@@ -366,3 +366,50 @@ def test_bench_line_contract_and_rccl_collation_path():
     assert par["batch_invariant"] and par["offending_boundaries_in_well_conditioned_utterances"] == 0, par
     pal = cb["parity_alignment_like"]
     assert pal["utterances"] == 2 and pal["word_boundaries"] > 0 and pal["within_one_frame"] == pal["word_boundaries"], pal
+
+
+def test_bench_collation_through_the_c_abi():
+    """bench.py --collate abi: the timed region's collation runs wca_allgather_results / wca_allreduce_counters (one rank, WCA_FORCE_DIST=1)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WCA_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29534")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "tiny", "--batch", "4", "--steps", "3", "--warmup", "1",
+                        "--distinct-batches", "2", "--seconds", "4", "--chars", "24", "--no-cpu-baseline", "--collate", "abi"], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    cfg = d["config"]
+    assert "C ABI" in cfg["collation"] and cfg["collated_utterances"] == 12
+    assert cfg["collective_calls"]["all_gather"] == 2 and cfg["collective_calls"]["all_reduce"] == 1
+
+
+def test_rccl_collation_through_the_c_abi(wca):
+    """wca_comm_* / wca_allgather_results / wca_allreduce_counters: the end-of-run collation straight from libwca.so over
+    librccl, no torch.distributed. One rank on this one-GPU box (a communicator of one): packed records survive the size gather +
+    padded all-gather, an EMPTY shard too, a buffer larger than the first capacity guess (the retry path), counters are summed, and
+    shard.allgather_results(..., engine=) takes this path."""
+    shard = _m("shard")
+    dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, _register=False)
+    uid = wca.WhisperAMD.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    model.comm_init(uid, 0, 1)
+    assert model.comm == (0, 1)
+    res = {5: (np.array([0.0, 0.7]), np.array([0.7, 1.38])), 2: (np.zeros(0), np.zeros(0)), 9: (np.array([1.5]), np.array([1.52]))}
+    before = dict(shard.COLLECTIVE_CALLS)
+    back = shard.allgather_results(res, engine=model)
+    assert sorted(back) == [2, 5, 9] and all(np.array_equal(back[k][0], res[k][0]) and np.array_equal(back[k][1], res[k][1]) for k in res)
+    assert shard.allgather_results({}, engine=model) == {}
+    rng = np.random.default_rng(0)
+    big = {i: (np.sort(rng.random(20)), np.sort(rng.random(20)) + 1.0) for i in range(400)}   # 131 KB packed: beyond the 64 KB first guess
+    back = shard.allgather_results(big, engine=model)
+    assert sorted(back) == list(range(400)) and all(np.array_equal(back[i][1], big[i][1]) for i in big)
+    assert shard.allreduce_counters(3, 5, 7, engine=model) == (3, 5, 7)
+    assert shard.COLLECTIVE_CALLS["all_gather"] == before["all_gather"] + 6 and shard.COLLECTIVE_CALLS["all_reduce"] == before["all_reduce"] + 1
+    with pytest.raises(wca._lib.WcaError, match="already has a communicator"):
+        model.comm_init(uid, 0, 1)
+    model.comm_destroy()
+    assert model.comm is None
+    with pytest.raises(wca._lib.WcaError, match="no communicator"):
+        model.allreduce_counters(1)

@@ -37,6 +37,7 @@ class DecodeOpts(C.Structure):
                 ("apply_timestamp_rules", C.c_int32), ("max_initial_timestamp_index", C.c_int32), ("no_speech", C.c_int32)]
 
 
+ERR_TOO_LONG = -2   # WCA_ERR_TOO_LONG
 AGGR_MEAN, AGGR_TOPK = 0, 1
 SITES = {"qkv": 0, "attention": 1, "out_proj": 2, "fc1": 3, "fc2": 4, "ln1": 5, "ln2": 6}  # WCA_SITE_* of include/wca.h
 DTYPE_F32, DTYPE_F16 = 0, 1
@@ -90,6 +91,11 @@ SIGNATURES = {
     "wca_set_precision": (_i, [_vp, _i]),
     "wca_get_precision": (_i, [_vp]),
     "wca_set_decode_mode": (_i, [_vp, _i, _i]),
+    "wca_comm_unique_id": (_i, [_vp]),
+    "wca_comm_init": (_i, [_vp, _vp, _i, _i]),
+    "wca_comm_destroy": (_i, [_vp]),
+    "wca_allgather_results": (_i, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
+    "wca_allreduce_counters": (_i, [_vp, C.POINTER(_i64), _i]),
     "wca_probe_strict_tp": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_double, _vp]),
     "wca_test_gemm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
 }

@@ -12,6 +12,8 @@
 //   weights_ws f32 [B][L*H][n_max][Fmax] filtered+softmaxed maps (timing.py:63-66; step-by-step API only)
 //   decode    f16 self-attention K/V cache [L][2][B][T_max][d], int32 token rows, fp32 logits [B][n_vocab]
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <chrono>
 #include <cmath>
@@ -213,6 +215,10 @@ struct wca_engine {
     int k1pad = 0;           // padded K of the split conv1 GEMM: windows of 3 frames x [hi(C) | lo(C)]
     std::vector<LayerW> enc, dec;  // only the half_t* members are used
   } sw;
+  // ---- collation over RCCL (wca_comm_init / wca_allgather_results): this engine's rank in a communicator of one rank per GPU
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 0;
+  GrowBuf coll_send, coll_recv;
   bool fuse_ln = true;       // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln; default on,
                              // never in split mode)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
@@ -1332,6 +1338,9 @@ void wca_engine_destroy(wca_engine* e) {
   for (GrowBuf* g : {&e->cap, &e->wws, &e->colnorm, &e->scores, &e->sel, &e->selsc, &e->matrix, &e->trace, &e->path, &e->pathlen,
                      &e->jump, &e->tmp0, &e->tmp1})
     g->release();
+  (void)wca_comm_destroy(e);
+  e->coll_send.release();
+  e->coll_recv.release();
   if (e->wslab) (void)hipFree(e->wslab);
   if (e->wslab2) (void)hipFree(e->wslab2);
   if (e->aslab) (void)hipFree(e->aslab);
@@ -2358,6 +2367,133 @@ int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, con
   int rc = wca_align_batch_enqueue(e, pcm_dev, pcm_stride, n_samples_host, tokens_dev, n_tok_max, n_tok_host, max_frames_host, batch, o);
   if (rc) return rc;
   return wca_align_batch_fetch(e, batch, n_tok_max, o->aggregation == WCA_AGGR_TOPK ? o->topk : 0, jump_frame_host, sel_idx_host);
+}
+
+// ---------------------------------------------------------------- collation over RCCL (no torch involved)
+namespace {
+// librccl is resolved at first use: the copy already in the process if there is one (torch links its own), else the system's
+struct RcclApi {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+RcclApi* rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api.h ? &api : nullptr;
+  tried = true;
+  const char* names[] = {"librccl.so", "librccl.so.1"};
+  for (const char* n : names)
+    if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+  for (const char* n : names)
+    if (!api.h) api.h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+  if (!api.h) return nullptr;
+  api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.h, "ncclGetUniqueId");
+  api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.h, "ncclCommInitRank");
+  api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.h, "ncclCommDestroy");
+  api.AllGather = (decltype(api.AllGather))dlsym(api.h, "ncclAllGather");
+  api.AllReduce = (decltype(api.AllReduce))dlsym(api.h, "ncclAllReduce");
+  api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.h, "ncclGetErrorString");
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.AllGather || !api.AllReduce || !api.GetErrorString) api.h = nullptr;
+  return api.h ? &api : nullptr;
+}
+#define RCCLCHK(api, expr)                                                                                              \
+  do {                                                                                                                  \
+    ncclResult_t _r = (expr);                                                                                           \
+    if (_r != ncclSuccess) return fail(WCA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, (api)->GetErrorString(_r), __FILE__, __LINE__); \
+  } while (0)
+}  // namespace
+
+int wca_comm_unique_id(uint8_t* id_out) {
+  if (!id_out) return fail(WCA_ERR_INVALID, "null argument");
+  RcclApi* r = rccl();
+  if (!r) return fail(WCA_ERR_STATE, "librccl.so could not be loaded");
+  static_assert(sizeof(ncclUniqueId) == WCA_COMM_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  RCCLCHK(r, r->GetUniqueId(&id));
+  memcpy(id_out, &id, sizeof(id));
+  return WCA_OK;
+}
+
+int wca_comm_init(wca_engine* e, const uint8_t* id_in, int rank, int world) {
+  if (!e || !id_in) return fail(WCA_ERR_INVALID, "null argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(WCA_ERR_INVALID, "rank %d outside [0, %d)", rank, world);
+  if (e->comm) return fail(WCA_ERR_STATE, "the engine already has a communicator (wca_comm_destroy first)");
+  RcclApi* r = rccl();
+  if (!r) return fail(WCA_ERR_STATE, "librccl.so could not be loaded");
+  HIPCHK(hipSetDevice(e->device));
+  ncclUniqueId id;
+  memcpy(&id, id_in, sizeof(id));
+  RCCLCHK(r, r->CommInitRank(&e->comm, world, id, rank));
+  e->comm_rank = rank;
+  e->comm_world = world;
+  return WCA_OK;
+}
+
+int wca_comm_destroy(wca_engine* e) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (!e->comm) return WCA_OK;
+  RcclApi* r = rccl();
+  if (r) {
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    (void)r->CommDestroy(e->comm);
+  }
+  e->comm = nullptr;
+  e->comm_world = 0;
+  return WCA_OK;
+}
+
+int wca_allgather_results(wca_engine* e, const uint8_t* packed_host, int64_t n_bytes, uint8_t* gathered_host, int64_t capacity_per_rank,
+                          int64_t* sizes_host) {
+  if (!e || !sizes_host || (n_bytes > 0 && !packed_host) || n_bytes < 0 || capacity_per_rank < 0) return fail(WCA_ERR_INVALID, "bad argument");
+  if (!e->comm) return fail(WCA_ERR_STATE, "no communicator: call wca_comm_init first");
+  RcclApi* r = rccl();
+  HIPCHK(hipSetDevice(e->device));
+  const int W = e->comm_world;
+  // (1) every rank's byte count
+  HIPCHK(e->coll_send.ensure(sizeof(int64_t)));
+  HIPCHK(e->coll_recv.ensure(sizeof(int64_t) * (size_t)W));
+  HIPCHK(hipMemcpyAsync(e->coll_send.p, &n_bytes, sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
+  RCCLCHK(r, r->AllGather(e->coll_send.p, e->coll_recv.p, 1, ncclInt64, e->comm, e->stream));
+  HIPCHK(hipMemcpyAsync(sizes_host, e->coll_recv.p, sizeof(int64_t) * (size_t)W, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  int64_t mx = 0;
+  for (int i = 0; i < W; ++i) mx = sizes_host[i] > mx ? sizes_host[i] : mx;
+  // every rank takes the same branch: the sizes are identical everywhere
+  if (mx > capacity_per_rank) return fail(WCA_ERR_TOO_LONG, "a rank packed %lld bytes, the gather buffer holds %lld per rank (sizes are in sizes_host: retry)", (long long)mx, (long long)capacity_per_rank);
+  if (mx == 0) return WCA_OK;
+  if (!gathered_host) return fail(WCA_ERR_INVALID, "null gather buffer");
+  // (2) the packed records, padded to the largest count
+  const size_t pad = (size_t)((mx + 15) / 16 * 16);
+  HIPCHK(e->coll_send.ensure(pad));
+  HIPCHK(e->coll_recv.ensure(pad * (size_t)W));
+  HIPCHK(hipMemsetAsync(e->coll_send.p, 0, pad, e->stream));
+  if (n_bytes > 0) HIPCHK(hipMemcpyAsync(e->coll_send.p, packed_host, (size_t)n_bytes, hipMemcpyHostToDevice, e->stream));
+  RCCLCHK(r, r->AllGather(e->coll_send.p, e->coll_recv.p, pad, ncclUint8, e->comm, e->stream));
+  for (int i = 0; i < W; ++i)
+    if (sizes_host[i] > 0)
+      HIPCHK(hipMemcpyAsync(gathered_host + (size_t)i * (size_t)capacity_per_rank, (const char*)e->coll_recv.p + (size_t)i * pad, (size_t)sizes_host[i],
+                            hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
+}
+
+int wca_allreduce_counters(wca_engine* e, int64_t* counters_host, int n) {
+  if (!e || !counters_host || n < 1 || n > 64) return fail(WCA_ERR_INVALID, "bad argument");
+  if (!e->comm) return fail(WCA_ERR_STATE, "no communicator: call wca_comm_init first");
+  RcclApi* r = rccl();
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(e->coll_send.ensure(sizeof(int64_t) * 64));
+  HIPCHK(hipMemcpyAsync(e->coll_send.p, counters_host, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, e->stream));
+  RCCLCHK(r, r->AllReduce(e->coll_send.p, e->coll_send.p, (size_t)n, ncclInt64, ncclSum, e->comm, e->stream));
+  HIPCHK(hipMemcpyAsync(counters_host, e->coll_send.p, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream));
+  return WCA_OK;
 }
 
 // ---------------------------------------------------------------- kernel-level test entry points

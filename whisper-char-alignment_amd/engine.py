@@ -402,6 +402,51 @@ class WhisperAMD:
         _lib.check(self._lib.wca_last_kernel_ms(self._h, _lib.SITES[site], C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
         return n.value, ms.value, fl.value, by.value
 
+    # ---- collation over RCCL through the C ABI (no torch.distributed involved; shard.allgather_results(..., engine=self))
+    @staticmethod
+    def comm_unique_id():
+        """128-byte id of a new communicator (rank 0 creates it; hand it to the other ranks by any side channel)."""
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.load().wca_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        _lib.check(self._lib.wca_comm_init(self._h, buf, int(rank), int(world)))
+        self._comm = (int(rank), int(world))
+        return self
+
+    def comm_destroy(self):
+        _lib.check(self._lib.wca_comm_destroy(self._h))
+        self._comm = None
+
+    @property
+    def comm(self):
+        """(rank, world) of this engine's RCCL communicator, or None."""
+        return getattr(self, "_comm", None)
+
+    def allgather_packed(self, packed):
+        """packed: uint8 numpy array of this rank -> list of every rank's uint8 array (wca_allgather_results)."""
+        rank, world = self._comm
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        sizes = (C.c_int64 * world)()
+        cap = max(int(packed.size), 1 << 16)
+        self._bind_stream()
+        while True:
+            out = np.zeros((world, cap), dtype=np.uint8)
+            rc = self._lib.wca_allgather_results(self._h, packed.ctypes.data_as(C.c_void_p), int(packed.size), out.ctypes.data_as(C.c_void_p), cap, sizes)
+            if rc == _lib.ERR_TOO_LONG:   # some rank packed more than `cap` bytes (every rank sees the same sizes): retry with room
+                cap = max(int(v) for v in sizes)
+                continue
+            _lib.check(rc)
+            return [out[r, :int(sizes[r])].copy() for r in range(world)]
+
+    def allreduce_counters(self, *counters):
+        arr = (C.c_int64 * len(counters))(*[int(v) for v in counters])
+        self._bind_stream()
+        _lib.check(self._lib.wca_allreduce_counters(self._h, arr, len(counters)))
+        return tuple(int(v) for v in arr)
+
     def set_precision(self, mode):
         """'f16' (default): operands rounded to f16 once, fp32 accumulation. 'split': reference precision -- every operand as an
         f16 (hi, lo) pair against the exact f16 weights, three-pass attention (wca.h: wca_set_precision). No batch may be in

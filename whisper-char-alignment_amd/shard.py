@@ -61,9 +61,17 @@ def unpack_results(buf):
     return out
 
 
-def allgather_results(local_results, device=None):
+def allgather_results(local_results, device=None, engine=None):
     """Collates every rank's {utt_index: (starts, ends)} on all ranks. Two collectives: an all-gather of
-    the packed byte counts, then one all-gather of the buffers padded to the maximum count."""
+    the packed byte counts, then one all-gather of the buffers padded to the maximum count.
+    engine: a WhisperAMD whose RCCL communicator is up (engine.comm_init): the C ABI's wca_allgather_results does both
+    collectives (ncclAllGather straight from libwca.so); default: torch.distributed on the initialised process group."""
+    if engine is not None and engine.comm is not None:
+        out = {}
+        for part in engine.allgather_packed(pack_results(local_results)):
+            out.update(unpack_results(part))
+        COLLECTIVE_CALLS["all_gather"] += 2
+        return out
     import torch.distributed as dist
     if _single_process(dist):
         return dict(local_results)
@@ -86,8 +94,11 @@ def allgather_results(local_results, device=None):
     return out
 
 
-def allreduce_counters(corrects, total_preds, total_gts, device=None):
+def allreduce_counters(corrects, total_preds, total_gts, device=None, engine=None):
     """Sums the evaluation counters over ranks (they are plain python ints in the reference)."""
+    if engine is not None and engine.comm is not None:
+        COLLECTIVE_CALLS["all_reduce"] += 1
+        return engine.allreduce_counters(corrects, total_preds, total_gts)
     import torch.distributed as dist
     if _single_process(dist):
         return corrects, total_preds, total_gts
