@@ -288,3 +288,36 @@ def test_pipelined_encode_decode_align(pkg, small, fake_vocab):
     # the ordinary path still works afterwards (slots were released by the fetches)
     j2, _ = m.align_batch(batches[0][0], batches[0][1], tokens, [len(row)] * B, [170] * B, o)
     assert np.array_equal(j2, serial[0][2])
+
+
+def test_asr_flow_in_reference_precision_mode(pkg, small):
+    """wca_set_precision(SPLIT) with the ASR pre-pass: the encoder and the cross-K/V run in split precision (rows [hi | lo]), the
+    greedy decode itself computes in f16 on the hi halves (whisper.decode runs fp16 too), and the alignment that re-uses the state
+    (pcm = NULL) runs in split precision. The decoded rows agree with the default mode's up to near-ties of the f16 logits, and the
+    re-using alignment gives exactly the frames of a split-mode alignment from the PCM."""
+    m, sd, dims = small
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    decoding, tok, opts, sup, blank = _setup(pkg, dims)
+    B = 3
+    pcm = torch.from_numpy(np.stack([syn.synth_audio(70 + b, n_samples=56000) for b in range(B)]).astype(np.float32)).cuda()
+    ns = [56000] * B
+    initial = list(tok.sot_sequence)
+    kw = dict(sample_len=8, eot=tok.eot, timestamp_begin=tok.timestamp_begin, apply_timestamp_rules=True, max_initial_timestamp_index=50)
+    text_tokens = [tok.encode(c)[0] for c in "ab cd ef"]
+    row = [*tok.sot_sequence, tok.no_timestamps, *text_tokens, tok.eot]
+    tokens = torch.tensor([row] * B, dtype=torch.int64, device="cuda")
+    o = m.make_opts(aggregation="topk", topk=3, sot_len=len(tok.sot_sequence), medfilt_width=3)
+    t16, n16, lp16 = m.greedy_decode(None, pcm, ns, initial, sup, blank, **kw)
+    m.align_batch(None, None, tokens, [len(row)] * B, [170] * B, o)   # consume the state
+    m.set_precision("split")
+    try:
+        ts, nsplit, lps = m.greedy_decode(None, pcm, ns, initial, sup, blank, **kw)
+        j_reuse, sel_reuse = m.align_batch(None, None, tokens, [len(row)] * B, [170] * B, o)
+        j_pcm, sel_pcm = m.align_batch(pcm, ns, tokens, [len(row)] * B, [170] * B, o)
+        assert np.array_equal(j_reuse, j_pcm) and np.array_equal(sel_reuse, sel_pcm)
+        assert ts.shape == t16.shape and (ts[:, :len(initial)] == np.array(initial)).all()
+        agree = float(np.mean(ts == t16))
+        assert agree >= 0.85, agree
+        np.testing.assert_allclose(lps, lp16, rtol=0.1, atol=0.2)
+    finally:
+        m.set_precision("f16")
