@@ -358,7 +358,9 @@ def _attn_ref(q, k, v, H, causal):
     # ragged shapes (query / key counts not multiples of the 128-row block / 64-key tile, a single key tile, one query row)
     (2, 3, 150, 200, 1 << 8, 0), (2, 3, 150, 200, 2 << 8, 0), (2, 6, 1500, 1500, 1 << 8, 0), (1, 2, 97, 33, 2 << 8, 0),
     (1, 2, 33, 1500, 2 << 8, 0), (3, 1, 129, 64, 2 << 8, 0), (1, 5, 2, 65, 2 << 8, 0), (1, 20, 1500, 1500, 2 << 8, 0),
-    (1, 2, 300, 1500, 2 << 8, 0), (1, 3, 700, 129, 2 << 8, 0), (2, 3, 257, 200, 2 << 8, 0), (1, 2, 64, 192, 2 << 8, 0)])
+    (1, 2, 300, 1500, 2 << 8, 0), (1, 3, 700, 129, 2 << 8, 0), (2, 3, 257, 200, 2 << 8, 0), (1, 2, 64, 192, 2 << 8, 0),
+    # 3 << 8 = the 32x32x16 kernel with the row sums on the vector ALU (the default form since round 3; 2 << 8 keeps them on the matrix pipe)
+    (2, 3, 150, 200, 3 << 8, 0), (1, 2, 97, 33, 3 << 8, 0), (1, 5, 2, 65, 3 << 8, 0), (1, 20, 1500, 1500, 3 << 8, 0), (2, 3, 257, 200, 3 << 8, 0)])
 def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     g = torch.Generator().manual_seed(nq * 13 + nk)
     d = H * 64
@@ -404,7 +406,7 @@ def test_attention_rescale_branch_forced(eng, lib, wca):
     vh = v.double().view(B, S, H, 64).permute(0, 2, 1, 3)
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 0.125, -1) @ vh).permute(0, 2, 1, 3).reshape(B, S, d)
     qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         out = torch.full((B, S, d), float("nan"), dtype=torch.float16, device="cuda")
         wca._lib.check(lib.wca_test_attention(eng._h, _vp(qd), _vp(kd), _vp(vd), _vp(out), None, 0, 0, B, H, S, S, variant << 8))
         torch.cuda.synchronize()

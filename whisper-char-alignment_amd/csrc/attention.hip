@@ -415,7 +415,18 @@ struct IntC {
   static constexpr int value = V;
 };
 
-template <bool STAMP>
+__device__ __forceinline__ float xor32_sumf(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// VSUM (the default since round 3; AttnArgs.variant 2 keeps the matrix-pipe form for A/B): row sums as fp32 VALU adds of the lane's 32
+// probabilities per tile (per-lane partial, the two lane halves of a row combined once at the end) instead of four `ones x P^T` MFMAs per
+// tile -- a fifth of the tile's matrix work, and the 32x32x16 MFMA is the expensive instruction under DVFS (profiles/r03_mfma_shapes.txt).
+// Interleaved A/B at 64 x 16 x 1500 x 1500 (tools/attn_ab.py 64 10 2,3): 0.708 vs 0.724 ms median on one box, 0.701 vs 0.699 on another:
+// between neutral and +2 %.
+template <bool STAMP, bool VSUM = false>
 __global__ __launch_bounds__(256) void attn32_kernel(AttnArgs a) {
   constexpr int NW = 4;  // waves per workgroup, 32 query rows each
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -623,12 +634,19 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnArgs a) {
     // p = exp2(s' - m); P^T fragment of k-step s (16 keys): registers 8 (s&1) .. +7 of key block s >> 1
     half8 pf[4];
     {
+      float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[s4][j] = (half_t)__builtin_amdgcn_exp2f(st[s4 >> 1][8 * (s4 & 1) + j]);
-      // row sums on the matrix pipe: D[i][q] = sum_k P^T[k][q] for every i (the f16-rounded probabilities that enter P.V)
-      {
+        for (int j = 0; j < 8; ++j) {
+          const float p = __builtin_amdgcn_exp2f(st[s4 >> 1][8 * (s4 & 1) + j]);
+          pf[s4][j] = (half_t)p;
+          if (VSUM) ps[j & 3] += p;
+        }
+      if (VSUM) {
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+      } else {
+        // row sums on the matrix pipe: D[i][q] = sum_k P^T[k][q] for every i (the f16-rounded probabilities that enter P.V)
         f32x16 rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[0], zero16, 0, 0, 0);
 #pragma unroll
         for (int s4 = 1; s4 < 4; ++s4) rs = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[s4], rs, 0, 0, 0);
@@ -669,7 +687,7 @@ __global__ __launch_bounds__(256) void attn32_kernel(AttnArgs a) {
 
   // ---- epilogue: ot[db][r] = O[q = l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]; the two halves of a row are swapped pairwise
   // (v_permlane32_swap) so that each lane stores 16 contiguous bytes
-  const float inv = 1.0f / l_run;
+  const float inv = 1.0f / (VSUM ? xor32_sumf(l_run) : l_run);
   half_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + h * 64;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
@@ -829,11 +847,12 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   // 32x32x16 one (tests)
   static const int env_variant = getenv("WCA_ATTN_VARIANT") ? atoi(getenv("WCA_ATTN_VARIANT")) : 0;  // debugging aid
   const int variant = a.variant ? a.variant : env_variant;
-  const bool use32 = !a.causal && !cap && (a.o_rs % 8) == 0 && variant != 1 && (a.nq >= 64 || variant == 2);
+  const bool use32 = !a.causal && !cap && (a.o_rs % 8) == 0 && variant != 1 && (a.nq >= 64 || variant >= 2);
   if (use32) {
     dim3 g32(((a.nq + 127) / 128) * a.H * a.B), b32(256);
     if (a.dbg) hipLaunchKernelGGL((attn32_kernel<true>), g32, b32, shmem, s, a);
-    else hipLaunchKernelGGL((attn32_kernel<false>), g32, b32, shmem, s, a);
+    else if (variant == 2) hipLaunchKernelGGL((attn32_kernel<false, false>), g32, b32, shmem, s, a);  // row sums on the matrix pipe (A/B, tests)
+    else hipLaunchKernelGGL((attn32_kernel<false, true>), g32, b32, shmem, s, a);                     // default (and variant 3)
     return hipGetLastError();
   }
   if (a.dbg) {
