@@ -131,10 +131,12 @@ def test_align_batch_matches_stepwise_api(wca, setup):
         assert w2 == words
         assert np.array_equal(st2, st) and np.array_equal(en2, en)
         assert list(sel[i]) == [l * dims.n_text_head + h for _, (l, h), _ in scores]
-        # the drop-in single-utterance call agrees on the maps up to fp32 summation order
+        # the drop-in single-utterance call takes other GEMM kernels (another fp32 summation order); in this f16-operand mode a
+        # last-bit difference of one GEMM moves f16 roundings downstream, so the maps agree to a fraction of the mode's own
+        # 3e-3 operand noise (measured 1e-4 ... 2e-4), not to fp32 precision (the split mode does: tests/test_batch_invariance_gpu.py)
         mel1 = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=model)
         w1, _ = tm.get_attentions(mel1, torch.tensor(toks).cuda(), model, tok, frames[i], medfilt_width=3)
-        assert (w1 - w).abs().max().item() < 1e-4
+        assert (w1 - w).abs().max().item() < 1e-3
 
 
 def test_too_long_is_rejected(wca, setup):
