@@ -293,8 +293,8 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f1
                           int out_mode, unsigned long long* dbg_dev);
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL.
  * causal: bit 0 = causal mask; bits 8-9 = kernel variant (0 auto, 1 the 16x16x32-MFMA kernel, 2 the 32x32x16-MFMA
- * kernel that serves the encoder's un-masked self-attention with its row sums on the matrix pipe, 3 the same with the row
- * sums on the vector ALU = what auto picks) */
+ * kernel that serves the encoder's un-masked self-attention = what auto picks, 3 the same with the row sums on the vector
+ * ALU: an experiment that was not adopted) */
 int wca_test_attention(wca_engine* e, const void* q_dev, const void* k_dev, const void* v_dev, void* o_dev,
                        float* cap_dev, int cap_ld, int cap_cols, int B, int H, int nq, int nk, int causal);
 /* split-mode attention (attention_split.hip): q2,k2,v2 [B][n][2*H*64] f16 rows [hi(H*64) | lo(H*64)] -> o2 [B][nq][2*H*64]

@@ -359,7 +359,7 @@ def _attn_ref(q, k, v, H, causal):
     (2, 3, 150, 200, 1 << 8, 0), (2, 3, 150, 200, 2 << 8, 0), (2, 6, 1500, 1500, 1 << 8, 0), (1, 2, 97, 33, 2 << 8, 0),
     (1, 2, 33, 1500, 2 << 8, 0), (3, 1, 129, 64, 2 << 8, 0), (1, 5, 2, 65, 2 << 8, 0), (1, 20, 1500, 1500, 2 << 8, 0),
     (1, 2, 300, 1500, 2 << 8, 0), (1, 3, 700, 129, 2 << 8, 0), (2, 3, 257, 200, 2 << 8, 0), (1, 2, 64, 192, 2 << 8, 0),
-    # 3 << 8 = the 32x32x16 kernel with the row sums on the vector ALU (the default form since round 3; 2 << 8 keeps them on the matrix pipe)
+    # 3 << 8 = the 32x32x16 kernel with the row sums on the vector ALU (an experiment kept for A/B; auto = 2 << 8, sums on the matrix pipe)
     (2, 3, 150, 200, 3 << 8, 0), (1, 2, 97, 33, 3 << 8, 0), (1, 5, 2, 65, 3 << 8, 0), (1, 20, 1500, 1500, 3 << 8, 0), (2, 3, 257, 200, 3 << 8, 0)])
 def test_attention(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     g = torch.Generator().manual_seed(nq * 13 + nk)

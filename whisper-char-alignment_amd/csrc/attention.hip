@@ -421,11 +421,12 @@ __device__ __forceinline__ float xor32_sumf(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// VSUM (the default since round 3; AttnArgs.variant 2 keeps the matrix-pipe form for A/B): row sums as fp32 VALU adds of the lane's 32
-// probabilities per tile (per-lane partial, the two lane halves of a row combined once at the end) instead of four `ones x P^T` MFMAs per
-// tile -- a fifth of the tile's matrix work, and the 32x32x16 MFMA is the expensive instruction under DVFS (profiles/r03_mfma_shapes.txt).
-// Interleaved A/B at 64 x 16 x 1500 x 1500 (tools/attn_ab.py 64 10 2,3): 0.708 vs 0.724 ms median on one box, 0.701 vs 0.699 on another:
-// between neutral and +2 %.
+// VSUM (experiment, AttnArgs.variant 3; NOT the default): row sums as fp32 VALU adds of the lane's 32 probabilities per tile (per-lane
+// partial, the two lane halves of a row combined once at the end) instead of four `ones x P^T` MFMAs per tile -- a fifth of the tile's
+// matrix work. Interleaved A/B at 64 x 16 x 1500 x 1500 (tools/attn_ab.py 64 10 2,3): 0.708 vs 0.724 ms median on one box, 0.701 vs 0.699 on
+// another. Rejected for its numerics: the MFMA form sums exactly the f16-rounded probabilities that enter P.V, so the rounding of P cancels
+// between numerator and denominator (a row dominated by one key returns that V row exactly); summing the unrounded fp32 values adds
+// ~2^-12 relative noise per layer, and the bench's 301-utterance f16 parity leg went from 58 to 139 boundaries outside one frame with it.
 template <bool STAMP, bool VSUM = false>
 __global__ __launch_bounds__(256) void attn32_kernel(AttnArgs a) {
   constexpr int NW = 4;  // waves per workgroup, 32 query rows each
@@ -851,8 +852,8 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   if (use32) {
     dim3 g32(((a.nq + 127) / 128) * a.H * a.B), b32(256);
     if (a.dbg) hipLaunchKernelGGL((attn32_kernel<true>), g32, b32, shmem, s, a);
-    else if (variant == 2) hipLaunchKernelGGL((attn32_kernel<false, false>), g32, b32, shmem, s, a);  // row sums on the matrix pipe (A/B, tests)
-    else hipLaunchKernelGGL((attn32_kernel<false, true>), g32, b32, shmem, s, a);                     // default (and variant 3)
+    else if (variant == 3) hipLaunchKernelGGL((attn32_kernel<false, true>), g32, b32, shmem, s, a);  // row sums on the vector ALU (experiment)
+    else hipLaunchKernelGGL((attn32_kernel<false, false>), g32, b32, shmem, s, a);                  // default: row sums on the matrix pipe
     return hipGetLastError();
   }
   if (a.dbg) {
