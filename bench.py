@@ -493,7 +493,11 @@ def main():
     model.set_precision(args.precision)
     if args.no_overlap:
         model.set_overlap(False)
-    model.set_fuse_ln(not args.no_fuse_ln)
+    # LayerNorms inside the residual GEMMs' epilogues: an in-launch hand-off between workgroups that needs the GPU to itself
+    # (include/wca.h, wca_set_fuse_ln) -- on when every rank has its own device, off in a shared-device rehearsal
+    shared_device = world > max(torch.cuda.device_count(), 1)
+    fuse_ln = not args.no_fuse_ln and not shared_device
+    model.set_fuse_ln(fuse_ln)
     if args.dec_unfused:
         model.set_decode_mode(False, 1)
     coll_engine = None
@@ -578,7 +582,7 @@ def main():
 
     def kernel_table(sites, precision):
         sym = dict(SITE_SYMBOL)
-        if precision == "split" or args.no_fuse_ln:   # separate LayerNorm launches: the residual GEMMs are the <2, ...> kernels
+        if precision == "split" or not fuse_ln:   # separate LayerNorm launches: the residual GEMMs are the <2, ...> kernels
             for k_ in ("out_proj", "fc2"):
                 sym[k_] = sym[k_].replace("gemm256p_f16_kernel<3,", "gemm256p_f16_kernel<2,")
         if precision == "split":
@@ -622,6 +626,8 @@ def main():
                                                       "achieved / frac count ALGORITHMIC flops, the MFMA pipe executes 2x (GEMM) / 3x (attention) of them)"),
                        "batch_per_gpu": args.batch, "utterances_per_step": world * args.batch, "parallelism": "dp%d (utterance shards)" % world,
                        "streams": "one (no overlap)" if args.no_overlap else "phase 1 / phase 2 overlapped on two streams",
+                       "layernorm": ("fused into the residual GEMMs' epilogues (wca_set_fuse_ln(1): this rank has its GPU to itself)" if fuse_ln and args.precision == "f16"
+                                     else "separate launches" + (" (ranks share a device)" if shared_device else "")),
                        "collation": "shard.allgather_results + allreduce_counters (product path), inside the timed region; "
                                     + ("through the C ABI (wca_allgather_results / wca_allreduce_counters: ncclAllGather / ncclAllReduce from libwca.so)"
                                        if coll_engine is not None else "torch.distributed collectives" if dist is not None else "one rank: passthrough"),

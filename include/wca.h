@@ -336,11 +336,15 @@ enum {
 };
 int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms, double* flops_per_launch,
                        double* bytes_per_launch);
-/* on (default): the encoder's LayerNorms run in the epilogue of the GEMM that produces their input (attention
- * out-projection -> mlp_ln, fc2 -> the next layer's attn_ln / ln_post) where the shape allows it (>= 192 tiles,
- * N % 256 == 0; otherwise, and always in split mode, the separate launches); off: separate LayerNorm launches everywhere.
- * Results agree up to fp32 rounding of the row statistics (a last-bit difference of a few f16 outputs per thousand).
- * Measured at the bench configuration: -0.15 ms per encoder layer at kernel level. */
+/* on: the encoder's LayerNorms run in the epilogue of the GEMM that produces their input (attention out-projection ->
+ * mlp_ln, fc2 -> the next layer's attn_ln / ln_post) where the shape allows it (>= 192 tiles, N % 256 == 0; otherwise, and
+ * always in split mode, the separate launches); off (default): separate LayerNorm launches everywhere. Results agree up to
+ * fp32 rounding of the row statistics (a last-bit difference of a few f16 outputs per thousand). Measured at the bench
+ * configuration: -0.15 ms per encoder layer at kernel level, +0.9 % end to end; bench.py turns it on.
+ * REQUIRES THE GPU TO ITSELF: the N / 256 workgroups of a 256-row panel wait for each other inside the launch, so all of them
+ * must be resident together. Kernels of the same engine never prevent that for long (they are short and finite), but a second
+ * process or engine running the same kind of launch on the device can hold the CUs its siblings need: the spin is bounded
+ * (seconds) and the batch then fails with WCA_ERR_HIP instead of hanging (observed with two bench ranks sharing one GPU). */
 int wca_set_fuse_ln(wca_engine* e, int on);
 /* Arithmetic of the model forward (reference: timing.py:58, `model(mel.unsqueeze(0), tokens.unsqueeze(0))` -- an fp32
  * forward of a checkpoint whose weights are f16 at rest):

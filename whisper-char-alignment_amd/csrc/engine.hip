@@ -219,8 +219,10 @@ struct wca_engine {
   ncclComm_t comm = nullptr;
   int comm_rank = 0, comm_world = 0;
   GrowBuf coll_send, coll_recv;
-  bool fuse_ln = true;       // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln; default on,
-                             // never in split mode)
+  bool fuse_ln = false;      // LayerNorm in the epilogue of the residual GEMMs where the shape allows (wca_set_fuse_ln; never in split
+                             // mode). OFF by default: the workgroups of a row panel wait for each other inside the launch, which needs
+                             // the GPU to itself -- with a second process (or engine) on the device two such launches can hold each
+                             // other's CUs and run into the bounded spin's time-out (measured: two bench ranks on one GPU)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run

@@ -462,7 +462,7 @@ class WhisperAMD:
         return "split" if self._lib.wca_get_precision(self._h) == 1 else "f16"
 
     def set_fuse_ln(self, on):
-        """LayerNorm in the residual GEMMs' epilogue (the default, where the shape allows) or as separate launches."""
+        """LayerNorm in the residual GEMMs' epilogue (needs the GPU to itself: wca.h) or as separate launches (the default)."""
         _lib.check(self._lib.wca_set_fuse_ln(self._h, 1 if on else 0))
 
     def set_overlap(self, on):
