@@ -360,6 +360,7 @@ def parity_alignment_like(args, wca, dims, syn, audio_mod, tok_mod, retok, timin
     from oracle import timing_ref, whisper_ref, tokenizer_ref
     sd = syn.aligned_state_dict(dims, seed=0)
     model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch).load_state_dict(sd)
+    model.set_precision(args.precision)
     ref = whisper_ref.WhisperRef(sd, dims)
     tok = tok_mod.get_tokenizer(True, language="English")
     rtok = tokenizer_ref.CharTokenizer()
@@ -397,7 +398,8 @@ def parity_alignment_like(args, wca, dims, syn, audio_mod, tok_mod, retok, timin
         print("alignment-like parity utterance %d/%d" % (j + 1, len(ids)), file=sys.stderr, flush=True)
     del model
     torch.cuda.empty_cache()
-    return {"checkpoint": "synthetic.aligned_state_dict(seed=0): 12 planted alignment heads, ridge at 7 frames per token", "utterances": len(ids),
+    return {"checkpoint": "synthetic.aligned_state_dict(seed=0): 12 planted alignment heads, ridge at 7 frames per token", "precision": args.precision,
+            "utterances": len(ids),
             "word_boundaries": total, "within_one_frame": within, "identical": identical, "utterances_with_identical_head_selection": heads_same,
             "mean_span_of_aligned_words_s": float(np.mean(span)) if span else None}
 
