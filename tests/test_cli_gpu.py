@@ -202,7 +202,7 @@ def test_infer_ali_pipeline_throughput(wca, tmp_path):
         r["utterances"], r["seconds"], rate_cli, rate_bench, rate_cli / rate_bench)
     print(line)
     if os.path.isdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")):
-        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r02_cli_throughput.txt"), "a") as f:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_cli_throughput.txt"), "a") as f:
             f.write(line + "\n")
     assert r["utterances"] == n_utt
     assert rate_cli >= 0.8 * rate_bench, line
