@@ -405,3 +405,22 @@ def test_alignment_head_tables_equal_the_published_masks():
         d = eng.dims_for(name)
         assert eng.decode_alignment_heads(dump, d.n_text_layer, d.n_text_head) == eng.ALIGNMENT_HEADS[name], name
     assert eng.ALIGNMENT_HEADS["large"] == eng.ALIGNMENT_HEADS["large-v3"]
+
+
+def test_bench_helpers_flop_accounting_and_core_count():
+    """bench.py's executed-FLOP figure (SURVEY 8d formulas minus what the fused path elides) and its measured core count."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    eng = importlib.import_module("whisper-char-alignment_amd.engine")
+
+    class A:
+        chars = 64
+    t = bench.executed_tflop_per_utt(eng.dims_for("medium"), A)
+    # SURVEY 8d: encoder 1.1381 + decoder 0.2103 TFLOP (logits 0.0073 not run); elided tail of the last decoder layer ~4.6 GFLOP
+    assert 1.340 < t < 1.349, t
+    assert abs((1.1381 + 0.2103) - t - 0.0046) < 0.0008
+    used, measured, override = bench.host_cores(0)
+    assert used == measured >= 1 and override is None
+    used, measured, override = bench.host_cores(3)
+    assert used == 3 and override == 3 and measured >= 1
