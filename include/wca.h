@@ -359,9 +359,37 @@ int wca_set_fuse_ln(wca_engine* e, int on);
  *     ~2.3x the MFMA work, twice the operand memory and a second copy of the weights ([N][2K]).
  * The greedy ASR pre-pass (wca_greedy_decode) computes in f16 in both modes, like whisper.decode's fp16 default.
  * Switching re-creates the activation arena: no batch may be in flight, encoded-but-unconsumed states are dropped. */
-enum { WCA_PRECISION_F16 = 0, WCA_PRECISION_SPLIT = 1 };
+enum { WCA_PRECISION_F16 = 0, WCA_PRECISION_SPLIT = 1, WCA_PRECISION_MIXED = 2 };
 int wca_set_precision(wca_engine* e, int mode);
-int wca_get_precision(wca_engine* e);
+int wca_get_precision(wca_engine* e);  /* F16: no site is split; SPLIT: every site; MIXED: some (wca_get_precision_sites) */
+/* Per-site precision control: WHICH stages of the forward of timing.py:58 carry their operands as (hi, lo) pairs. A set bit
+ * puts that stage on reference-precision arithmetic (above); a clear bit leaves it on single f16 operands. Seams need no
+ * conversion pass: a producer stores the pair when its consumer is split (every GEMM / LayerNorm / log-mel epilogue can), a
+ * single-precision consumer of a pair buffer reads the hi halves (hi IS f16(x)), and a split GEMM behind a single-precision
+ * attention reads the single f16 rows it got.
+ *   LOGMEL     log-mel DFT + filterbank sums in f64 (dataset.py:46-48 -> whisper.log_mel_spectrogram)
+ *   CONV       conv stem: conv1 + GELU, conv2 + GELU + positional embedding (AudioEncoder.forward)
+ *   ENC_GEMM   encoder blocks >= enc_first_layer: attn_ln / mlp_ln outputs as pairs, QKV / out-projection / fc1 / fc2 K-doubled
+ *   ENC_ATTN   encoder blocks >= enc_first_layer: three-pass self-attention on q / k / v pairs
+ *   CROSS_KV   ln_post output as pairs + the fused cross-attention key / value projection of every decoder layer K-doubled
+ *   DEC        teacher-forced decoder: its LayerNorms, QKV / out / cross-query / cross-out / MLP GEMMs and causal self-attention
+ *   CAPTURE    the hooked cross-attention (timing.py:50-55): q and the cross K / V rows as pairs, three-pass q.k^T (the captured
+ *              logits) and P.V
+ * wca_set_precision(SPLIT) == wca_set_precision_sites(WCA_PSITE_ALL, 0); F16 == mask 0. enc_first_layer in [0, n_audio_layer].
+ * Same state rules as wca_set_precision (no batch in flight). The arena is widened (and the K-doubled weight copies exist)
+ * whenever any bit is set. */
+enum {
+  WCA_PSITE_LOGMEL = 1,
+  WCA_PSITE_CONV = 2,
+  WCA_PSITE_ENC_GEMM = 4,
+  WCA_PSITE_ENC_ATTN = 8,
+  WCA_PSITE_CROSS_KV = 16,
+  WCA_PSITE_DEC = 32,
+  WCA_PSITE_CAPTURE = 64,
+  WCA_PSITE_ALL = 127
+};
+int wca_set_precision_sites(wca_engine* e, unsigned mask, int enc_first_layer);
+int wca_get_precision_sites(wca_engine* e, unsigned* mask_out, int* enc_first_layer_out);
 /* on (default): phase 2 (decoder, post-processing, DTW) of a batch runs on the engine's second stream beside the next
  * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
  * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */

@@ -301,3 +301,85 @@ def test_split_mode_closes_the_headline_parity_gap(wca):
     bad = [o for o in off_split if o[0] not in excused]
     assert not bad, (bad, excused)
     del model
+
+
+SITE_ROWS = [
+    # (sites, first encoder block of the ENC_* bits)
+    ("capture", 0), ("dec", 0), ("cross_kv", 0), ("cross_kv,capture", 0), ("dec,cross_kv,capture", 0), ("logmel,conv", 0), ("enc_attn", 0),
+    ("enc_gemm", 0), ("enc_gemm,enc_attn", 2), ("enc_attn,dec,cross_kv,capture", 1), ("enc_gemm,capture", 1), ("logmel,conv,enc_gemm,enc_attn", 0),
+]
+
+
+def test_precision_sites_seams_small_dims(wca):
+    """wca_set_precision_sites: every stage can be switched to (hi, lo) operand pairs on its own; the seams between split and
+    single-precision stages need no conversion pass (a producer writes pairs exactly when its consumer is split; a single-precision
+    consumer of a pair buffer reads the hi halves). Small model (256 wide, 3 + 3 layers), step-by-step API and the fused batch path:
+      * mask ALL == wca_set_precision(SPLIT), mask 0 == F16, bit for bit;
+      * every mixed row gives finite maps whose distance to the fp32 oracle is at most the f16 mode's (plus noise) and at least ~the
+        full split mode's, and the fused batch path agrees with the step-by-step API of the same row;
+      * the decoder-side rows (CAPTURE + CROSS_KV + DEC) bring the captured logits' contribution down: maps error well below f16's."""
+    from oracle import timing_ref, whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
+    sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    tok = tk.get_tokenizer(True, language="English")
+    ref = whisper_ref.WhisperRef(sd, dims)
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 7, 80000, 40)
+    F = len(pcm) // 320
+    ref_mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), audio.mel_filters(80))
+    rw, _ = timing_ref.get_attentions(ref_mel, torch.tensor(tokens), ref, F, 3, 1.0)
+    tdev = torch.tensor(tokens).cuda()
+
+    def maps():
+        w, _ = tm.get_attentions(ref_mel.cuda(), tdev, model, tok, F, medfilt_width=3)
+        return w.cpu()
+
+    w_f16 = maps()
+    model.set_precision("split")
+    assert model.precision_sites == (["logmel", "conv", "enc_gemm", "enc_attn", "cross_kv", "dec", "capture"], 0)
+    w_split = maps()
+    model.set_precision_sites("all", 0)
+    assert model.precision == "split" and torch.equal(maps(), w_split)
+    model.set_precision_sites(0)
+    assert model.precision == "f16" and torch.equal(maps(), w_f16)
+    e16, esp = (w_f16 - rw).abs().max().item(), (w_split - rw).abs().max().item()
+    # fused batch path, ragged batch
+    specs = [(31, 48000, 25), (32, 80000, 40), (33, 32000, 12)]
+    utts = [_utt(syn, rt, tok, u, n, c) for u, n, c in specs]
+    n_max, smax = max(len(u[3]) for u in utts), max(len(u[0]) for u in utts)
+    pb = np.zeros((3, smax), dtype=np.float32)
+    tarr = np.full((3, n_max), tok.eot, dtype=np.int64)
+    for i, (p, _, _, toks) in enumerate(utts):
+        pb[i, :len(p)] = p
+        tarr[i, :len(toks)] = toks
+    n_samples, n_tok, frames = [len(u[0]) for u in utts], [len(u[3]) for u in utts], [len(u[0]) // 320 for u in utts]
+    opts = model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3)
+    report = []
+    for sites, first in SITE_ROWS:
+        model.set_precision_sites(sites, first)
+        assert model.precision == "mixed" and model.precision_sites[0] == sites.split(",")
+        w = maps()
+        assert torch.isfinite(w).all(), sites
+        err = (w - rw).abs().max().item()
+        report.append("%s@%d %.1e" % (sites, first, err))
+        assert err <= 1.5 * e16 + 1e-6, (sites, err, e16)
+        assert err >= 0.2 * esp, (sites, err, esp)
+        if "capture" in sites and "cross_kv" in sites and "dec" in sites and "enc" not in sites:
+            assert err < 0.7 * e16, (sites, err, e16)   # the decoder side's own rounding is gone; the encoder's remains
+        jump, sel = model.align_batch(torch.from_numpy(pb).cuda(), n_samples, torch.from_numpy(tarr).cuda(), n_tok, frames, opts)
+        for i, (p, _t, tt_i, toks) in enumerate(utts):
+            mel_i = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=model)
+            w_i, _ = tm.get_attentions(mel_i, torch.tensor(toks).cuda(), model, tok, frames[i], medfilt_width=3)
+            _wd, st_i, en_i, _m, sc_i = tm.force_align(w_i, tt_i, tok, "char", "topk", topk=4)
+            _w2, st2, en2 = tm.words_from_jump_frames(jump[i], tt_i, tok, "char")
+            assert np.array_equal(st2, st_i) and np.array_equal(en2, en_i), (sites, i)
+            assert list(sel[i]) == [l * dims.n_text_head + h for _, (l, h), _ in sc_i], (sites, i)
+    print("maps vs fp32 oracle: f16 %.1e, split %.1e; mixed: %s" % (e16, esp, "; ".join(report)))
+    with pytest.raises(ValueError):
+        model.set_precision_sites("nope")
+    with pytest.raises(RuntimeError):
+        model.set_precision_sites("enc_gemm", 99)
+    model.set_precision("f16")
+    assert torch.equal(maps(), w_f16)
+    del model

@@ -39,6 +39,7 @@ class DecodeOpts(C.Structure):
 
 ERR_TOO_LONG = -2   # WCA_ERR_TOO_LONG
 AGGR_MEAN, AGGR_TOPK = 0, 1
+PRECISION_SITES = {"logmel": 1, "conv": 2, "enc_gemm": 4, "enc_attn": 8, "cross_kv": 16, "dec": 32, "capture": 64}  # WCA_PSITE_*
 SITES = {"qkv": 0, "attention": 1, "out_proj": 2, "fc1": 3, "fc2": 4, "ln1": 5, "ln2": 6}  # WCA_SITE_* of include/wca.h
 DTYPE_F32, DTYPE_F16 = 0, 1
 
@@ -90,6 +91,8 @@ SIGNATURES = {
     "wca_set_fuse_ln": (_i, [_vp, _i]),
     "wca_set_precision": (_i, [_vp, _i]),
     "wca_get_precision": (_i, [_vp]),
+    "wca_set_precision_sites": (_i, [_vp, C.c_uint, _i]),
+    "wca_get_precision_sites": (_i, [_vp, C.POINTER(C.c_uint), C.POINTER(C.c_int)]),
     "wca_set_decode_mode": (_i, [_vp, _i, _i]),
     "wca_comm_unique_id": (_i, [_vp]),
     "wca_comm_init": (_i, [_vp, _vp, _i, _i]),

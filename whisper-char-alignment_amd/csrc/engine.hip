@@ -207,7 +207,9 @@ struct wca_engine {
   // hi = f16(x), lo = f16(x - hi) in ONE row [hi(K) | lo(K)], and every weight matrix as [W | W] ([N][2K], built once on the
   // device from the f16 weights, which are exact): A.W^T = [A_hi | A_lo].[W | W]^T is then a K-doubled call of the SAME GEMM
   // kernels with f16 x f16 products exact in the fp32 accumulator. Activation operand buffers are twice as wide.
-  bool split = false;
+  bool split = false;        // some site is split (sites != 0): the arena is wide and the K-doubled weight copies exist
+  unsigned sites = 0;        // WCA_PSITE_* bits: which stages run on (hi, lo) operand pairs (wca_set_precision_sites)
+  int enc_from = 0;          // encoder blocks >= enc_from take the ENC_GEMM / ENC_ATTN bits
   char* wslab2 = nullptr;    // the K-doubled weight copies (allocated while split is on)
   bool sw_dirty = true;      // a weight was (re)loaded since the copies were built
   struct SplitW {
@@ -240,6 +242,23 @@ T* carve(char*& cur, size_t count, size_t align = 256) {
   T* r = reinterpret_cast<T*>(p);
   cur = reinterpret_cast<char*>(p + count * sizeof(T));
   return r;
+}
+
+// ---- per-site precision (wca_set_precision_sites): which stages compute on (hi, lo) operand pairs
+inline bool site_on(const wca_engine* e, unsigned bit) { return (e->sites & bit) != 0; }
+inline bool enc_gemm_split(const wca_engine* e, int li) { return (e->sites & WCA_PSITE_ENC_GEMM) && li >= e->enc_from && li < e->dims.n_audio_layer; }
+inline bool enc_attn_split(const wca_engine* e, int li) { return (e->sites & WCA_PSITE_ENC_ATTN) && li >= e->enc_from && li < e->dims.n_audio_layer; }
+
+// Operands of one GEMM at a seam. a_pair: the A buffer holds [hi(K) | lo(K)] rows (row stride 2 K); want: the GEMM's site is
+// split. Both: the K-doubled product [A_hi | A_lo] [W | W]^T. A single-precision site behind a pair producer reads the hi halves
+// (hi IS f16(x)); a split site behind a single-precision producer multiplies the f16 rows it got (there is no lo to add).
+struct GemmOpnd {
+  const half_t* W;
+  int lda, K, ldw;
+};
+inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K) {
+  const bool use = a_pair && want;
+  return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K};
 }
 
 // ---- weight slab layout (two passes: size, then carve)
@@ -521,7 +540,7 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
 // ev_gemm / ev_ln (profiling): event slots {site, layer} for the GEMM and for the LayerNorm launch; the fused kernel is timed
 // as the GEMM's site alone.
 int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, float* x, int M, int N,
-                     int K, const float* gamma, const float* beta, half_t* xn, int site, bool allow_fused = true, int ev_gemm_site = -1,
+                     int K, const float* gamma, const float* beta, half_t* xn, bool ln_pair, int site, bool allow_fused = true, int ev_gemm_site = -1,
                      int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0) {
   auto ev = [&](int st, int li, int which) {
     if (e->profiling && st >= 0 && li >= 0 && li < 33) {
@@ -530,8 +549,8 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     }
   };
   ev(ev_gemm_site, ev_gemm_li, 0);
-  const int om = e->split ? 2 : 1;  // split mode: xn rows are [hi(N) | lo(N)] (K is already the doubled depth); no fused form
-  if (allow_fused && !e->split && gemm_ln_supported(M, N, K, e->n_cu)) {
+  const int om = ln_pair ? 2 : 1;  // the LayerNorm's consumer is split: xn rows are [hi(N) | lo(N)] (no fused form writes pairs)
+  if (allow_fused && !ln_pair && gemm_ln_supported(M, N, K, e->n_cu)) {
     GemmArgs g{};
     g.A = A;
     g.lda = lda;
@@ -560,7 +579,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
   HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes));
   ev(ev_gemm_site, ev_gemm_li, 1);
   ev(ev_ln_site, ev_ln_li, 0);
-  HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s, om * N, e->split ? N : 0));
+  HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s, om * N, ln_pair ? N : 0));
   ev(ev_ln_site, ev_ln_li, 1);
   return WCA_OK;
 }
@@ -656,44 +675,45 @@ int join_phase2(wca_engine* e) {
 }
 
 // ---- encoder: mel_tm (f16 time-major) -> xn = ln_post(x) (f16) and optionally x (f32)
-// Split mode (e->split): the same launches on [hi | lo] operand rows (row width om * width, lo half `width` elements after the
-// hi half) against the K-doubled weight copies; f16 outputs are stored as pairs (out_mode 4), the fp32 residual stream is as before.
+// Per-site precision (e->sites): a split stage runs the same launches on [hi | lo] operand rows (row width 2 * width, lo half
+// `width` elements after the hi half) against the K-doubled weight copies; a producer stores pairs (out_mode 4 / the LayerNorm's
+// lo_off) exactly when its consumer is split; the fp32 residual stream is the same in every mode.
 int run_encoder(wca_engine* e, int B) {
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, H = D.n_audio_head;
-  const bool sp = e->split;
-  const int om = sp ? 2 : 1;
+  const bool cv = site_on(e, WCA_PSITE_CONV);
+  const int omc = cv ? 2 : 1;
   hipStream_t s = e->stream;
   {
     GemmArgs g{};
     g.A = e->mel_tm;
-    g.lda = om * D.n_mels;
+    g.lda = omc * D.n_mels;
     g.a_rows_per_batch = N_FRAMES;
-    g.a_batch_stride = (long)(N_FRAMES + 2) * om * D.n_mels;
-    g.W = sp ? e->sw.conv1_w : e->conv1_w;
-    g.ldw = sp ? e->sw.k1pad : e->k1pad;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * omc * D.n_mels;
+    g.W = cv ? e->sw.conv1_w : e->conv1_w;
+    g.ldw = cv ? e->sw.k1pad : e->k1pad;
     g.bias = e->conv1_b;
-    g.C = e->h1pad + om * d;  // output frame t lands in padded row t + 1
-    g.ldc = om * d;
+    g.C = e->h1pad + omc * d;  // output frame t lands in padded row t + 1
+    g.ldc = omc * d;
     g.c_rows_per_batch = N_FRAMES;
-    g.c_batch_stride = (long)(N_FRAMES + 2) * om * d;
-    g.c_lo = sp ? d : 0;
+    g.c_batch_stride = (long)(N_FRAMES + 2) * omc * d;
+    g.c_lo = cv ? d : 0;
     g.M = B * N_FRAMES;
     g.N = d;
     g.K = g.ldw;
     g.gelu = 1;
-    g.out_mode = sp ? 4 : 0;
+    g.out_mode = cv ? 4 : 0;
     g.site = 3;
     HIPCHK(launch_gemm(g, s));
   }
   {
     GemmArgs g{};
     g.A = e->h1pad;
-    g.lda = 2 * om * d;  // stride 2
+    g.lda = 2 * omc * d;  // stride 2
     g.a_rows_per_batch = N_CTX;
-    g.a_batch_stride = (long)(N_FRAMES + 2) * om * d;
-    g.W = sp ? e->sw.conv2_w : e->conv2_w;
-    g.ldw = 3 * om * d;
+    g.a_batch_stride = (long)(N_FRAMES + 2) * omc * d;
+    g.W = cv ? e->sw.conv2_w : e->conv2_w;
+    g.ldw = 3 * omc * d;
     g.bias = e->conv2_b;
     g.C = e->x;
     g.ldc = d;
@@ -701,7 +721,7 @@ int run_encoder(wca_engine* e, int B) {
     g.pos_period = N_CTX;
     g.M = B * N_CTX;
     g.N = d;
-    g.K = 3 * om * d;
+    g.K = 3 * omc * d;
     g.gelu = 1;
     g.out_mode = 1;
     g.site = 3;
@@ -716,28 +736,35 @@ int run_encoder(wca_engine* e, int B) {
       e->kev_set[site][li] = true;
     }
   };
-  // LayerNorms ride in the epilogue of the GEMM that produces their input (gemm_residual_ln): mlp_ln in the attention
-  // out-projection, the NEXT layer's attn_ln (ln_post after the last layer) in fc2; only layer 0's attn_ln is a launch
-  const bool fuse_ln = e->fuse_ln && !sp;
-  mark(WCA_SITE_LN1, 0, 0);
-  HIPCHK(launch_layernorm_f16(e->x, e->enc[0].ln1_g, e->enc[0].ln1_b, e->xn, M, d, 1e-5f, s, om * d, sp ? d : 0));
-  mark(WCA_SITE_LN1, 0, 1);
+  // LayerNorms ride in the epilogue of the GEMM that produces their input (gemm_residual_ln) where wca_set_fuse_ln allows it and
+  // their consumer reads single f16 rows: mlp_ln in the attention out-projection, the NEXT layer's attn_ln (ln_post after the
+  // last layer) in fc2; only layer 0's attn_ln is always a launch
+  {
+    const bool p0 = enc_gemm_split(e, 0);
+    mark(WCA_SITE_LN1, 0, 0);
+    HIPCHK(launch_layernorm_f16(e->x, e->enc[0].ln1_g, e->enc[0].ln1_b, e->xn, M, d, 1e-5f, s, (p0 ? 2 : 1) * d, p0 ? d : 0));
+    mark(WCA_SITE_LN1, 0, 1);
+  }
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
-    const LayerW& w = sp ? e->sw.enc[li] : l;  // the f16 matrices ([N][K], or [N][2K] = [W | W] in split mode)
+    const bool gs = enc_gemm_split(e, li), as = enc_attn_split(e, li);
+    const LayerW& w2 = e->split ? e->sw.enc[li] : l;  // the K-doubled copies [N][2K] = [W | W] (present while any site is split)
+    const int oma = as ? 2 : 1;  // q / k / v rows and the attention output: pairs iff the attention is split
+    // q / k / v projection: xn is a pair buffer iff this layer's GEMMs are split (its LayerNorm wrote it for them)
+    const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d);
     mark(WCA_SITE_QKV, li, 0);
-    HIPCHK(gemm(s, e->xn, om * d, w.qkv_w, om * d, l.qkv_b, e->qkv, om * 3 * d, M, 3 * d, om * d, 0, 0, 1, nullptr, 0, sp ? 3 * d : 0));
+    HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0));
     mark(WCA_SITE_QKV, li, 1);
     AttnArgs a{};
     a.Q = e->qkv;
     a.K = e->qkv + d;
     a.V = e->qkv + 2 * d;
-    a.q_bs = a.k_bs = a.v_bs = (long)N_CTX * om * 3 * d;
-    a.q_rs = a.k_rs = a.v_rs = om * 3 * d;
+    a.q_bs = a.k_bs = a.v_bs = (long)N_CTX * oma * 3 * d;
+    a.q_rs = a.k_rs = a.v_rs = oma * 3 * d;
     a.O = e->att;
-    a.o_bs = (long)N_CTX * om * d;
-    a.o_rs = om * d;
-    a.split = sp ? 1 : 0;
+    a.o_bs = (long)N_CTX * oma * d;
+    a.o_rs = oma * d;
+    a.split = as ? 1 : 0;
     a.q_lo = a.k_lo = a.v_lo = 3 * d;
     a.o_lo = d;
     a.nq = N_CTX;
@@ -751,15 +778,20 @@ int run_encoder(wca_engine* e, int B) {
     mark(WCA_SITE_ATTN, li, 1);
     // sites OUT / FC2 = the GEMM alone (or the fused GEMM + LayerNorm kernel); the LayerNorm launches: mlp_ln = LN2[li], the next
     // layer's attn_ln / ln_post = LN1[li + 1]
-    if (int rc = gemm_residual_ln(e, s, e->att, om * d, w.out_w, om * d, l.out_b, e->x, M, d, om * d, l.ln2_g, l.ln2_b, e->xn, 1, fuse_ln, WCA_SITE_OUT,
-                                  li, WCA_SITE_LN2, li))
+    const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d);
+    if (int rc = gemm_residual_ln(e, s, e->att, oo.lda, oo.W, oo.ldw, l.out_b, e->x, M, d, oo.K, l.ln2_g, l.ln2_b, e->xn, gs, 1, e->fuse_ln, WCA_SITE_OUT, li,
+                                  WCA_SITE_LN2, li))
       return rc;
+    const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d);
     mark(WCA_SITE_FC1, li, 0);
-    HIPCHK(gemm(s, e->xn, om * d, w.fc1_w, om * d, l.fc1_b, e->hid, om * 4 * d, M, 4 * d, om * d, 1, 0, 1, nullptr, 0, sp ? 4 * d : 0));
+    HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
-    if (int rc = gemm_residual_ln(e, s, e->hid, om * 4 * d, w.fc2_w, om * 4 * d, l.fc2_b, e->x, M, d, om * 4 * d, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
-                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, 4, fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1))
+    // the LayerNorm behind fc2 feeds the next layer's q / k / v projection, or (ln_post) the cross-K/V projection
+    const bool next_pair = last ? site_on(e, WCA_PSITE_CROSS_KV) : enc_gemm_split(e, li + 1);
+    const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d);
+    if (int rc = gemm_residual_ln(e, s, e->hid, o2.lda, o2.W, o2.ldw, l.fc2_b, e->x, M, d, o2.K, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
+                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1))
       return rc;
   }
   return WCA_OK;
@@ -768,56 +800,60 @@ int run_encoder(wca_engine* e, int B) {
 // cross-attention K/V of every decoder layer in one GEMM: kv[b*1500 + t][(2l + {0,1})*dt + c]
 // skip_last_v: the value projection of the LAST decoder layer (the final dt columns) is only read by that layer's
 // P.V product, whose result nobody uses when the caller wants the captured logits but no output logits.
+// The rows are pairs [hi(L*2*dt) | lo(L*2*dt)] iff the hooked cross-attention (CAPTURE) is split.
 int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v = false) {
   if (!kvbuf) kvbuf = e->kv;
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
   const int n_cols = L * 2 * dt - (skip_last_v ? dt : 0);
-  const bool sp = e->split;
-  const int om = sp ? 2 : 1;  // split: rows [hi(L*2*dt) | lo(L*2*dt)]
-  HIPCHK(gemm(e->stream, e->xn, om * d, sp ? e->sw.kv_w : e->kv_w, om * d, e->kv_b, kvbuf, om * L * 2 * dt, B * N_CTX, n_cols, om * d, 0, 0, 3, nullptr, 0,
-              sp ? (long)L * 2 * dt : 0));
+  const bool ks = site_on(e, WCA_PSITE_CROSS_KV), cs = site_on(e, WCA_PSITE_CAPTURE);
+  const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d);
+  HIPCHK(gemm(e->stream, e->xn, o.lda, o.W, o.ldw, e->kv_b, kvbuf, (cs ? 2 : 1) * L * 2 * dt, B * N_CTX, n_cols, o.K, 0, 0, 3, nullptr, 0,
+              cs ? (long)L * 2 * dt : 0));
   return WCA_OK;
 }
 
-// The teacher-forced decoder in split mode: separate LayerNorm launches writing [hi | lo] rows, the tile GEMMs on the K-doubled
-// weight copies (the few-row kernel of gemm_rows.hip has no pair output), attn_split_kernel for both attentions. The captured
-// logits are the three-pass fp32 sums.
-int run_decoder_split(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out, hipStream_t s,
+// The teacher-forced decoder with a split site (DEC: its LayerNorms / GEMMs / causal self-attention on pairs; CAPTURE: the hooked
+// cross-attention on q / K / V pairs): separate LayerNorm launches, the tile GEMMs (the few-row kernel of gemm_rows.hip has no pair
+// output), attn_split_kernel where the attention is split. The captured logits of a split CAPTURE are the three-pass fp32 sums.
+int run_decoder_sites(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* cap, int Fpad, int Fcap, float* logits_out, hipStream_t s,
                       const half_t* kvbuf) {
   const wca_model_dims& D = e->dims;
   const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
   const int M = B * n;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
-  const int kv_ld = 2 * L * 2 * dt;
+  const bool gs = site_on(e, WCA_PSITE_DEC), cs = site_on(e, WCA_PSITE_CAPTURE);
+  const int omg = gs ? 2 : 1, omx = cs ? 2 : 1;
+  const int kv_ld = omx * L * 2 * dt;
   const long kv_lo = (long)L * 2 * dt;
   HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
   auto ln = [&](const float* g, const float* b) -> int {
-    HIPCHK(launch_layernorm_f16(e->xd, g, b, e->xdn, M, dt, 1e-5f, s, 2 * dt, dt));
+    HIPCHK(launch_layernorm_f16(e->xd, g, b, e->xdn, M, dt, 1e-5f, s, omg * dt, gs ? dt : 0));
     return WCA_OK;
   };
-  // C = A W2^T (+ bias ...): A rows [hi | lo] of K2 = 2 K elements, W2 = [W | W]; c_lo > 0: f16 pair output
-  auto mm = [&](const half_t* A, int lda, const half_t* W2, const float* bias, void* C, int ldc, int N, int K2, int gelu, int out_mode, long c_lo,
-                int site) -> int {
-    HIPCHK(gemm(s, A, lda, W2, K2, bias, C, ldc, M, N, K2, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo));
+  // C = A W^T (+ bias ...): a_pair = the A buffer holds [hi | lo] rows of K values each; c_lo > 0: f16 pair output
+  auto mm = [&](const half_t* A, bool a_pair, const half_t* W1, const half_t* W2, const float* bias, void* C, int ldc, int N, int K, int gelu, int out_mode,
+                long c_lo, int site) -> int {
+    const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K);
+    HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo));
     return WCA_OK;
   };
   for (int li = 0; li < L; ++li) {
     const LayerW& l = e->dec[li];
     const LayerW& w = e->sw.dec[li];
     WCA_TRY(ln(l.ln1_g, l.ln1_b));
-    WCA_TRY(mm(e->xdn, 2 * dt, w.qkv_w, l.qkv_b, e->qkv_d, 6 * dt, 3 * dt, 2 * dt, 0, 0, 3 * dt, 2));
+    WCA_TRY(mm(e->xdn, gs, l.qkv_w, w.qkv_w, l.qkv_b, e->qkv_d, omg * 3 * dt, 3 * dt, dt, 0, 0, gs ? 3 * dt : 0, 2));
     {
       AttnArgs a{};
       a.Q = e->qkv_d;
       a.K = e->qkv_d + dt;
       a.V = e->qkv_d + 2 * dt;
-      a.q_bs = a.k_bs = a.v_bs = (long)n * 6 * dt;
-      a.q_rs = a.k_rs = a.v_rs = 6 * dt;
+      a.q_bs = a.k_bs = a.v_bs = (long)n * omg * 3 * dt;
+      a.q_rs = a.k_rs = a.v_rs = omg * 3 * dt;
       a.O = e->att_d;
-      a.o_bs = (long)n * 2 * dt;
-      a.o_rs = 2 * dt;
-      a.split = 1;
+      a.o_bs = (long)n * omg * dt;
+      a.o_rs = omg * dt;
+      a.split = gs ? 1 : 0;
       a.q_lo = a.k_lo = a.v_lo = 3 * dt;
       a.o_lo = dt;
       a.nq = n;
@@ -828,22 +864,22 @@ int run_decoder_split(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
       a.causal = 1;
       HIPCHK(launch_attention(a, s));
     }
-    WCA_TRY(mm(e->att_d, 2 * dt, w.out_w, l.out_b, e->xd, dt, dt, 2 * dt, 0, 2, 0, 2));
+    WCA_TRY(mm(e->att_d, gs, l.out_w, w.out_w, l.out_b, e->xd, dt, dt, dt, 0, 2, 0, 2));
     WCA_TRY(ln(l.lnc_g, l.lnc_b));
-    WCA_TRY(mm(e->xdn, 2 * dt, w.cq_w, l.cq_b, e->q_d, 2 * dt, dt, 2 * dt, 0, 0, dt, 2));
+    WCA_TRY(mm(e->xdn, gs, l.cq_w, w.cq_w, l.cq_b, e->q_d, omx * dt, dt, dt, 0, 0, cs ? dt : 0, 2));
     {
       AttnArgs a{};
       a.Q = e->q_d;
-      a.q_bs = (long)n * 2 * dt;
-      a.q_rs = 2 * dt;
+      a.q_bs = (long)n * omx * dt;
+      a.q_rs = omx * dt;
       a.K = kvbuf + (size_t)(2 * li) * dt;
       a.V = kvbuf + (size_t)(2 * li + 1) * dt;
       a.k_bs = a.v_bs = (long)N_CTX * kv_ld;
       a.k_rs = a.v_rs = kv_ld;
       a.O = e->att_d;
-      a.o_bs = (long)n * 2 * dt;
-      a.o_rs = 2 * dt;
-      a.split = 1;
+      a.o_bs = (long)n * omx * dt;
+      a.o_rs = omx * dt;
+      a.split = cs ? 1 : 0;
       a.q_lo = dt;
       a.k_lo = a.v_lo = kv_lo;
       a.o_lo = dt;
@@ -861,14 +897,14 @@ int run_decoder_split(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
       HIPCHK(launch_attention(a, s));
     }
     if (li == L - 1 && !logits_out) break;
-    WCA_TRY(mm(e->att_d, 2 * dt, w.co_w, l.co_b, e->xd, dt, dt, 2 * dt, 0, 2, 0, 2));
+    WCA_TRY(mm(e->att_d, cs, l.co_w, w.co_w, l.co_b, e->xd, dt, dt, dt, 0, 2, 0, 2));
     WCA_TRY(ln(l.ln2_g, l.ln2_b));
-    WCA_TRY(mm(e->xdn, 2 * dt, w.fc1_w, l.fc1_b, e->hid_d, 8 * dt, 4 * dt, 2 * dt, 1, 0, 4 * dt, 2));
-    WCA_TRY(mm(e->hid_d, 8 * dt, w.fc2_w, l.fc2_b, e->xd, dt, dt, 8 * dt, 0, 2, 0, 2));
+    WCA_TRY(mm(e->xdn, gs, l.fc1_w, w.fc1_w, l.fc1_b, e->hid_d, omg * 4 * dt, 4 * dt, dt, 1, 0, gs ? 4 * dt : 0, 2));
+    WCA_TRY(mm(e->hid_d, gs, l.fc2_w, w.fc2_w, l.fc2_b, e->xd, dt, dt, 4 * dt, 0, 2, 0, 2));
   }
   if (logits_out) {
     WCA_TRY(ln(e->lnf_g, e->lnf_b));
-    WCA_TRY(mm(e->xdn, 2 * dt, e->sw.tok_emb, nullptr, logits_out, D.n_vocab, D.n_vocab, 2 * dt, 0, 1, 0, 3));
+    WCA_TRY(mm(e->xdn, gs, e->tok_emb, e->sw.tok_emb, nullptr, logits_out, D.n_vocab, D.n_vocab, dt, 0, 1, 0, 3));
   }
   return WCA_OK;
 }
@@ -880,7 +916,7 @@ int run_decoder(wca_engine* e, const int64_t* tokens_dev, int B, int n, float* c
   const int dt = D.n_text_state, H = D.n_text_head, L = D.n_text_layer;
   if (!s) s = e->stream;
   if (!kvbuf) kvbuf = e->kv;
-  if (e->split) return run_decoder_split(e, tokens_dev, B, n, cap, Fpad, Fcap, logits_out, s, kvbuf);
+  if (site_on(e, WCA_PSITE_DEC) || site_on(e, WCA_PSITE_CAPTURE)) return run_decoder_sites(e, tokens_dev, B, n, cap, Fpad, Fcap, logits_out, s, kvbuf);
   const int M = B * n;
   const float scale = 1.0f / std::sqrt((float)(dt / H));
   HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
@@ -966,7 +1002,7 @@ int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, c
   half_t* q_d = e->q_d + (size_t)b0 * dt;
   half_t* hid_d = e->hid_d + (size_t)b0 * 4 * dt;
   // split mode: the cross-K/V rows are [hi | lo]; the greedy pre-pass (whisper.decode runs in fp16 itself) reads the hi halves
-  const int kv_ld = (e->split ? 2 : 1) * L * 2 * dt;
+  const int kv_ld = (site_on(e, WCA_PSITE_CAPTURE) ? 2 : 1) * L * 2 * dt;
   const half_t* kvb = kvbuf + (size_t)b0 * N_CTX * kv_ld;
   if (phase == -2 || phase == -1)
     HIPCHK(launch_embed_step(tokens + (size_t)b0 * T_max, T_max, t, e->tok_emb, e->dec_pos, xd, B, dt, D.n_vocab, s));
@@ -1063,9 +1099,10 @@ int run_logmel(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const in
   a.twiddle = e->twiddle;
   a.mel_out = mel_out;
   a.mel_tm = want_tm ? e->mel_tm : nullptr;
-  a.n_mels_pad = (e->split ? 2 : 1) * e->dims.n_mels;
-  a.tm_lo = e->split ? e->dims.n_mels : 0;
-  a.precise = e->split ? 1 : 0;
+  const bool cv = site_on(e, WCA_PSITE_CONV);  // the conv stem reads pairs
+  a.n_mels_pad = (cv ? 2 : 1) * e->dims.n_mels;
+  a.tm_lo = cv ? e->dims.n_mels : 0;
+  a.precise = site_on(e, WCA_PSITE_LOGMEL) ? 1 : 0;
   a.scratch = e->mel_scratch;
   a.gmax = e->gmax;
   a.n_mels = e->dims.n_mels;
@@ -1092,8 +1129,8 @@ int mel_to_tm(wca_engine* e, const float* mel_dev, int batch) {
   const wca_model_dims& D = e->dims;
   const size_t nel = (size_t)D.n_mels * N_FRAMES;
   dim3 grid((unsigned)((nel + 255) / 256), batch);
-  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch, (e->split ? 2 : 1) * D.n_mels,
-                     e->split ? D.n_mels : 0);
+  const bool cv = site_on(e, WCA_PSITE_CONV);
+  hipLaunchKernelGGL(mel_to_tm_kernel, grid, dim3(256), 0, e->stream, mel_dev, e->mel_tm, D.n_mels, batch, (cv ? 2 : 1) * D.n_mels, cv ? D.n_mels : 0);
   HIPCHK(hipGetLastError());
   return WCA_OK;
 }
@@ -1447,11 +1484,13 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   return WCA_OK;
 }
 
-int wca_set_precision(wca_engine* e, int mode) {
+int wca_set_precision_sites(wca_engine* e, unsigned mask, int enc_first_layer) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
-  if (mode != WCA_PRECISION_F16 && mode != WCA_PRECISION_SPLIT) return fail(WCA_ERR_INVALID, "precision mode %d", mode);
-  const bool want = mode == WCA_PRECISION_SPLIT;
-  if (want == e->split) return WCA_OK;
+  if (mask & ~(unsigned)WCA_PSITE_ALL) return fail(WCA_ERR_INVALID, "precision site mask 0x%x has unknown bits", mask);
+  if (enc_first_layer < 0 || enc_first_layer > e->dims.n_audio_layer)
+    return fail(WCA_ERR_INVALID, "enc_first_layer %d outside [0, %d]", enc_first_layer, e->dims.n_audio_layer);
+  if (!(mask & (WCA_PSITE_ENC_GEMM | WCA_PSITE_ENC_ATTN))) enc_first_layer = 0;  // (unused: keep the state canonical)
+  if (mask == e->sites && enc_first_layer == e->enc_from) return WCA_OK;
   if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the batches in flight before changing the precision mode");
   for (auto& st : e->enc_q)
     if (!st.decoded) return fail(WCA_ERR_STATE, "an encoded batch is waiting: consume it before changing the precision mode");
@@ -1459,32 +1498,76 @@ int wca_set_precision(wca_engine* e, int mode) {
   HIPCHK(hipStreamSynchronize(e->stream));
   HIPCHK(hipStreamSynchronize(e->stream2));
   HIPCHK(hipStreamSynchronize(e->stream3));
-  for (auto& st : e->enc_q) e->slot_busy[st.slot] = false;  // decoded-but-never-aligned states die with the arena
+  const bool want = mask != 0;
+  if (want != e->split) {
+    // The activation arena is laid out per mode (operand buffers are twice as wide while any site is split) and the K-doubled
+    // weight copies exist only then. Allocate the NEW arena (and copies) first; the old ones are released and the engine's
+    // state committed only when both allocations succeeded, so a failed switch leaves a working engine in its previous mode.
+    const bool was = e->split;
+    e->split = want;
+    const size_t abytes = layout_arena(e, nullptr);
+    e->split = was;
+    char* na = nullptr;
+    char* nw = nullptr;
+    size_t wbytes = 0;
+    hipError_t he = hipMalloc((void**)&na, abytes);
+    if (he == hipSuccess && want) {
+      wbytes = layout_split_weights(e, nullptr);
+      he = hipMalloc((void**)&nw, wbytes);
+    }
+    if (he == hipSuccess) he = hipMemset(na, 0, abytes);  // zero pad rows of mel_tm / h1pad, counters, flags and all slack
+    if (he == hipSuccess && nw) he = hipMemset(nw, 0, wbytes);  // K padding of the conv1 copy stays zero
+    if (he != hipSuccess) {
+      if (na) (void)hipFree(na);
+      if (nw) (void)hipFree(nw);
+      (void)hipGetLastError();
+      layout_arena(e, e->aslab);  // (the sizing pass above moved the arena pointers: restore them)
+      if (was) layout_split_weights(e, e->wslab2);
+      return fail(WCA_ERR_HIP, "precision switch: allocating the %s arena (%zu + %zu bytes) failed: %s; the engine keeps its previous mode",
+                  want ? "wide" : "narrow", abytes, wbytes, hipGetErrorString(he));
+    }
+    (void)hipFree(e->aslab);
+    if (e->wslab2) (void)hipFree(e->wslab2);
+    e->aslab = na;
+    e->wslab2 = nw;
+    e->split = want;
+    layout_arena(e, e->aslab);
+    if (want) {
+      layout_split_weights(e, e->wslab2);
+      e->sw_dirty = true;  // built on the next entry point that runs the model (after the weights are final)
+    }
+    e->ln_err = nullptr;
+  } else if (want) {
+    // same arena, other row layouts inside it (a buffer's rows are [hi | lo] or single per site): the zero pad rows of the
+    // time-major conv images move with the row width, so wipe the arena once
+    const size_t abytes = layout_arena(e, nullptr);
+    layout_arena(e, e->aslab);
+    HIPCHK(hipMemset(e->aslab, 0, abytes));
+  }
+  for (auto& st : e->enc_q) e->slot_busy[st.slot] = false;  // decoded-but-never-aligned states die with the arena / its layout
   e->enc_q.clear();
-  // the activation arena is laid out per mode (operand buffers are twice as wide in split mode): re-create it
-  HIPCHK(hipFree(e->aslab));
-  e->aslab = nullptr;
-  if (e->wslab2) {
-    HIPCHK(hipFree(e->wslab2));
-    e->wslab2 = nullptr;
-  }
-  e->split = want;
-  const size_t abytes = layout_arena(e, nullptr);
-  HIPCHK(hipMalloc((void**)&e->aslab, abytes));
-  HIPCHK(hipMemset(e->aslab, 0, abytes));  // zero pad rows of mel_tm / h1pad, counters, flags and all slack
-  layout_arena(e, e->aslab);
-  e->ln_err = nullptr;
-  if (want) {
-    const size_t wbytes = layout_split_weights(e, nullptr);
-    HIPCHK(hipMalloc((void**)&e->wslab2, wbytes));
-    HIPCHK(hipMemset(e->wslab2, 0, wbytes));  // K padding of the conv1 copy stays zero
-    layout_split_weights(e, e->wslab2);
-    e->sw_dirty = true;  // built on the next entry point that runs the model (after the weights are final)
-  }
+  e->sites = mask;
+  e->enc_from = enc_first_layer;
   return WCA_OK;
 }
 
-int wca_get_precision(wca_engine* e) { return (e && e->split) ? WCA_PRECISION_SPLIT : WCA_PRECISION_F16; }
+int wca_get_precision_sites(wca_engine* e, unsigned* mask_out, int* enc_first_layer_out) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (mask_out) *mask_out = e->sites;
+  if (enc_first_layer_out) *enc_first_layer_out = e->enc_from;
+  return WCA_OK;
+}
+
+int wca_set_precision(wca_engine* e, int mode) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (mode != WCA_PRECISION_F16 && mode != WCA_PRECISION_SPLIT) return fail(WCA_ERR_INVALID, "precision mode %d", mode);
+  return wca_set_precision_sites(e, mode == WCA_PRECISION_SPLIT ? (unsigned)WCA_PSITE_ALL : 0u, 0);
+}
+
+int wca_get_precision(wca_engine* e) {
+  if (!e || e->sites == 0) return WCA_PRECISION_F16;
+  return (e->sites == (unsigned)WCA_PSITE_ALL && e->enc_from == 0) ? WCA_PRECISION_SPLIT : WCA_PRECISION_MIXED;
+}
 
 int wca_set_fuse_ln(wca_engine* e, int on) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
@@ -2772,7 +2855,7 @@ int wca_test_encoder(wca_engine* e, const float* mel_dev, int batch, float* xa_o
   if (rc) return rc;
   // xn holds ln_post(x) in f16 (split mode: hi + lo pairs); widen for the caller
   const size_t n = (size_t)batch * N_CTX * D.n_audio_state;
-  if (e->split)
+  if (site_on(e, WCA_PSITE_CROSS_KV))  // ln_post wrote pairs for the cross-K/V projection
     hipLaunchKernelGGL(widen_split_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, (size_t)batch * N_CTX, D.n_audio_state);
   else
     hipLaunchKernelGGL(widen_kernel, dim3(2048), dim3(256), 0, e->stream, e->xn, xa_out_dev, n);

@@ -457,9 +457,34 @@ class WhisperAMD:
         _lib.check(self._lib.wca_set_precision(self._h, modes[mode]))
         return self
 
+    def set_precision_sites(self, sites, enc_first_layer=0):
+        """Per-stage precision (wca.h: wca_set_precision_sites). `sites`: an iterable of names from _lib.PRECISION_SITES
+        ('logmel', 'conv', 'enc_gemm', 'enc_attn', 'cross_kv', 'dec', 'capture'), the string 'all', or the integer mask; the
+        named stages compute on (hi, lo) operand pairs, the others on single f16 operands. The encoder bits apply to blocks
+        >= enc_first_layer."""
+        if isinstance(sites, str):
+            sites = list(_lib.PRECISION_SITES) if sites == "all" else [x for x in sites.replace("+", ",").split(",") if x]
+        if isinstance(sites, int):
+            mask = sites
+        else:
+            unknown = [x for x in sites if x not in _lib.PRECISION_SITES]
+            if unknown:
+                raise ValueError("unknown precision site(s) %s (known: %s)" % (unknown, sorted(_lib.PRECISION_SITES)))
+            mask = 0
+            for x in sites:
+                mask |= _lib.PRECISION_SITES[x]
+        _lib.check(self._lib.wca_set_precision_sites(self._h, mask, int(enc_first_layer)))
+        return self
+
+    @property
+    def precision_sites(self):
+        mask, first = C.c_uint(0), C.c_int(0)
+        _lib.check(self._lib.wca_get_precision_sites(self._h, C.byref(mask), C.byref(first)))
+        return sorted((n for n, b in _lib.PRECISION_SITES.items() if mask.value & b), key=lambda n: _lib.PRECISION_SITES[n]), first.value
+
     @property
     def precision(self):
-        return "split" if self._lib.wca_get_precision(self._h) == 1 else "f16"
+        return {0: "f16", 1: "split", 2: "mixed"}[self._lib.wca_get_precision(self._h)]
 
     def set_fuse_ln(self, on):
         """LayerNorm in the residual GEMMs' epilogue (needs the GPU to itself: wca.h) or as separate launches (the default)."""
