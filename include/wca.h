@@ -262,11 +262,16 @@ int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capa
 int wca_comm_unique_id(uint8_t* id_out /* [WCA_COMM_ID_BYTES] */);
 int wca_comm_init(wca_engine* e, const uint8_t* id /* [WCA_COMM_ID_BYTES] */, int rank, int world);
 int wca_comm_destroy(wca_engine* e);
-/* gathered_host [world][capacity_per_rank]: rank r's sizes_host[r] bytes start at r * capacity_per_rank. WCA_ERR_TOO_LONG
- * (on every rank alike) when some rank packed more than capacity_per_rank bytes; sizes_host is filled: retry with room. */
+/* gathered_host [world][capacity_per_rank]: rank r's sizes_host[r] bytes start at r * capacity_per_rank. The first collective
+ * gathers every rank's {n_bytes, capacity_per_rank}; WCA_ERR_TOO_LONG is returned ON EVERY RANK ALIKE when the largest n_bytes
+ * exceeds the SMALLEST capacity any rank passed (the decision is wca_collate_plan on the gathered pairs, so all ranks issue the
+ * same sequence of collectives whatever their own capacity); sizes_host is filled: retry with max(sizes_host) everywhere. */
 int wca_allgather_results(wca_engine* e, const uint8_t* packed_host, int64_t n_bytes, uint8_t* gathered_host,
                           int64_t capacity_per_rank, int64_t* sizes_host /* [world] */);
 int wca_allreduce_counters(wca_engine* e, int64_t* counters_host /* [n], summed in place */, int n);
+/* The fit decision of wca_allgather_results as a pure host function (no GPU, no communicator): WCA_OK and *pad_out = the padded
+ * per-rank payload when max(sizes) <= min(capacities), else WCA_ERR_TOO_LONG (pad_out still set). Exported for the protocol tests. */
+int wca_collate_plan(const int64_t* sizes /* [world] */, const int64_t* capacities /* [world] */, int world, int64_t* pad_out);
 
 /* ---- kernel-level entry points (used by the parity tests and by bench.py's roofline leg) -------- */
 /* C[m][n] = sum_k A[m][k] W[n][k] (+bias) ; A,W f16 device. out_mode low byte: 0 f16 store, 1 f32 store,
@@ -275,6 +280,12 @@ int wca_allreduce_counters(wca_engine* e, int64_t* counters_host /* [n], summed 
  * with A = [A_hi | A_lo] ([M][2K]), W = [W | W] ([N][2K]) and K = 2K. */
 int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                   int N, int K, int gelu, int out_mode);
+/* The pair product with the W K-tiles staged ONCE (persistent 256 x 256 kernel, SPLITW form): a2 = [A_hi | A_lo] ([M][2K] f16),
+ * w = the PLAIN [N][K] matrix, K the algorithmic depth. out_mode as above (0, 1, 2, 4; >> 8: 0 auto, 257, 258).
+ * WCA_ERR_INVALID where that kernel does not apply (fewer than 192 256 x 256 tiles, K % 128 != 0): the engine then multiplies
+ * the K-doubled operands through wca_test_gemm's path. */
+int wca_test_gemm_pairs(wca_engine* e, const void* a2_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
+                        int N, int K, int gelu, int out_mode);
 /* x (f32 [M][N], read-modify-write) += A W^T + bias; xn (f16 [M][N]) = LayerNorm(x; gamma, beta, eps 1e-5): the residual
  * GEMMs of an encoder block with the LayerNorm in their epilogue (gemm_epilogue.h). site 1 / 4 = the out-projection's /
  * fc2's kernel symbol. WCA_ERR_INVALID where the fused form does not apply (N % 256, K % 128, fewer than 192 tiles). */

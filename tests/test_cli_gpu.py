@@ -387,8 +387,9 @@ def test_bench_collation_through_the_c_abi():
 def test_rccl_collation_through_the_c_abi(wca):
     """wca_comm_* / wca_allgather_results / wca_allreduce_counters: the end-of-run collation straight from libwca.so over
     librccl, no torch.distributed. One rank on this one-GPU box (a communicator of one): packed records survive the size gather +
-    padded all-gather, an EMPTY shard too, a buffer larger than the first capacity guess (the retry path), counters are summed, and
-    shard.allgather_results(..., engine=) takes this path."""
+    padded all-gather, an EMPTY shard too, a shard above the 64 KB capacity floor (at one rank the capacity is the shard's own size, so
+    nothing is retried here: the retry protocol between ranks with unequal shards is tests/test_distributed.py::
+    test_abi_collation_retry_is_collective), counters are summed, and shard.allgather_results(..., engine=) takes this path."""
     shard = _m("shard")
     dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
     model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, _register=False)
@@ -402,7 +403,7 @@ def test_rccl_collation_through_the_c_abi(wca):
     assert sorted(back) == [2, 5, 9] and all(np.array_equal(back[k][0], res[k][0]) and np.array_equal(back[k][1], res[k][1]) for k in res)
     assert shard.allgather_results({}, engine=model) == {}
     rng = np.random.default_rng(0)
-    big = {i: (np.sort(rng.random(20)), np.sort(rng.random(20)) + 1.0) for i in range(400)}   # 131 KB packed: beyond the 64 KB first guess
+    big = {i: (np.sort(rng.random(20)), np.sort(rng.random(20)) + 1.0) for i in range(400)}   # 131 KB packed: above the 64 KB capacity floor
     back = shard.allgather_results(big, engine=model)
     assert sorted(back) == list(range(400)) and all(np.array_equal(back[i][1], big[i][1]) for i in big)
     assert shard.allreduce_counters(3, 5, 7, engine=model) == (3, 5, 7)

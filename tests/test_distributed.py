@@ -156,3 +156,79 @@ def test_force_dist_keeps_the_collectives_for_one_rank(monkeypatch):
         assert shard.COLLECTIVE_CALLS["all_gather"] == before["all_gather"] + 2   # passthrough again
     finally:
         dist.destroy_process_group()
+
+
+def test_abi_collation_retry_is_collective():
+    """wca_allgather_results decides "does every shard fit" on the {size, capacity} pairs of ALL ranks
+    (wca_collate_plan), so ranks with unequal shards and unequal first capacity guesses take the same branch and issue the same
+    sequence of collectives. Two ranks are emulated by two threads that run the PRODUCT's WhisperAMD.allgather_packed against a stand-in
+    for the two RCCL calls (a barrier-synchronised exchange) whose fit decision is the library's own wca_collate_plan: shards of
+    160 000 and 100 000 bytes (capacities 160 000 and 100 000 on the first attempt: the old per-caller test let rank 0 go on to the
+    payload all-gather while rank 1 retried the size gather)."""
+    import ctypes as C
+    import threading
+    import types
+    wca = importlib.import_module("whisper-char-alignment_amd")
+    lib = wca._lib.load()
+    i64 = C.c_int64
+    # the pure decision, straight from libwca.so
+    pad = i64(0)
+    assert lib.wca_collate_plan((i64 * 2)(160000, 100000), (i64 * 2)(160000, 100000), 2, C.byref(pad)) == wca._lib.ERR_TOO_LONG and pad.value == 160000
+    assert lib.wca_collate_plan((i64 * 2)(160000, 100000), (i64 * 2)(160000, 160000), 2, C.byref(pad)) == 0 and pad.value == 160000
+    assert lib.wca_collate_plan((i64 * 2)(0, 0), (i64 * 2)(65536, 65536), 2, C.byref(pad)) == 0 and pad.value == 0
+    assert lib.wca_collate_plan((i64 * 3)(5, 70000, 1), (i64 * 3)(65536, 70000, 65536), 3, C.byref(pad)) == wca._lib.ERR_TOO_LONG
+
+    world = 2
+    bar = threading.Barrier(world)
+    board = {}
+    log = {r: [] for r in range(world)}
+
+    class FakeLib:
+        """wca_allgather_results with the two ncclAllGather calls replaced by a barrier exchange between the threads."""
+        def __init__(self, rank):
+            self.rank = rank
+
+        def wca_allgather_results(self, _h, packed_ptr, n_bytes, out_ptr, cap, sizes):
+            r = self.rank
+            log[r].append("gather {size, capacity}")
+            board[("pair", r)] = (int(n_bytes), int(cap))
+            bar.wait(timeout=30)
+            pairs = [board[("pair", i)] for i in range(world)]
+            bar.wait(timeout=30)
+            for i in range(world):
+                sizes[i] = pairs[i][0]
+            pad_ = i64(0)
+            rc = lib.wca_collate_plan((i64 * world)(*[p_[0] for p_ in pairs]), (i64 * world)(*[p_[1] for p_ in pairs]), world, C.byref(pad_))
+            if rc != 0:
+                return rc
+            if pad_.value == 0:
+                return 0
+            log[r].append("gather payload %d" % pad_.value)
+            board[("data", r)] = bytes((C.c_uint8 * int(n_bytes)).from_address(packed_ptr.value)) if n_bytes else b""
+            bar.wait(timeout=30)
+            for i in range(world):
+                d = board[("data", i)]
+                C.memmove(out_ptr.value + i * int(cap), d, len(d))
+            bar.wait(timeout=30)
+            return 0
+
+    shards = [np.arange(160000, dtype=np.uint32).astype(np.uint8), (np.arange(100000, dtype=np.uint32) * 7).astype(np.uint8)]
+    results, errors = {}, []
+
+    def run(rank):
+        try:
+            me = types.SimpleNamespace(_comm=(rank, world), _lib=FakeLib(rank), _h=None, _bind_stream=lambda: None)
+            results[rank] = wca.WhisperAMD.allgather_packed(me, shards[rank])
+        except Exception as exc:  # noqa: BLE001
+            errors.append((rank, repr(exc)))
+            bar.abort()
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert not errors, errors
+    assert log[0] == log[1] == ["gather {size, capacity}", "gather {size, capacity}", "gather payload 160000"], log
+    for r in range(world):
+        assert all(np.array_equal(results[r][i], shards[i]) for i in range(world))

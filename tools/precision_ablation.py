@@ -51,13 +51,20 @@ def oracle_word_times(args, sd, dims, syn, audio_mod, ids):
             print("oracle cache:", path, flush=True)
             return [(z["st_%d" % u], z["en_%d" % u], z["sc_%d" % u]) for u in ids], path
     torch.set_num_threads(min(len(os.sched_getaffinity(0)), 64))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    path = os.path.join(ROOT, "gpurun_out", key + ".npz")
+    part = path + ".part.npz"   # progress survives a time-out: re-running continues from it
+    store = dict(np.load(part, allow_pickle=False)) if os.path.exists(part) else {}
     tok = tokenizer_ref.CharTokenizer()
     ref = whisper_ref.WhisperRef(sd, dims)
     filt = audio_mod.mel_filters(dims.n_mels)
     n_samples = int(args.seconds * 16000)
-    out, store = [], {}
+    out = []
     t00 = time.time()
     for i, u in enumerate(ids):
+        if "st_%d" % u in store:
+            out.append((store["st_%d" % u], store["en_%d" % u], store["sc_%d" % u]))
+            continue
         pcm = torch.from_numpy(syn.synth_audio(u, n_samples))
         text = syn.synth_text(u, args.chars)
         mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(pcm), filt)
@@ -73,9 +80,10 @@ def oracle_word_times(args, sd, dims, syn, audio_mod, ids):
         store["st_%d" % u], store["en_%d" % u], store["sc_%d" % u] = out[-1]
         if i % 10 == 0:
             print("oracle utterance %d/%d (%.0f s)" % (i + 1, len(ids), time.time() - t00), flush=True)
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    path = os.path.join(ROOT, "gpurun_out", key + ".npz")
+            np.savez_compressed(part, **store)
     np.savez_compressed(path, **store)
+    if os.path.exists(part):
+        os.remove(part)
     return out, path
 
 
@@ -91,18 +99,22 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--rows", default="", help="comma-separated row names (default: every row of the table); 'sites:a+b@first' adds a row")
+    ap.add_argument("--oracle-only", action="store_true", help="compute / complete the oracle cache and stop (CPU only: runs without a GPU)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_precision_ablation.txt"))
     args = ap.parse_args()
 
     wca = importlib.import_module("whisper-char-alignment_amd")
     m = lambda n: importlib.import_module("whisper-char-alignment_amd." + n)  # noqa: E731
     syn, tok_mod, retok, timing, audio_mod = m("synthetic"), m("tokenizer"), m("retokenize"), m("timing"), m("audio")
-    device = torch.device("cuda", 0)
     dims = wca.dims_for(args.model)
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
     ids = list(range(args.first_id, args.first_id + args.utts))
     oracle, cache_path = oracle_word_times(args, sd, dims, syn, audio_mod, ids)
+    if args.oracle_only:
+        print("oracle word times:", cache_path)
+        return
 
+    device = torch.device("cuda", 0)
     model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch).load_state_dict(sd)
     tok = tok_mod.get_tokenizer(True, language="English")
     opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width, qk_scale=1.0)

@@ -78,6 +78,7 @@ SIGNATURES = {
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "wca_test_gemm_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_stamped": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "wca_comm_destroy": (_i, [_vp]),
     "wca_allgather_results": (_i, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     "wca_allreduce_counters": (_i, [_vp, C.POINTER(_i64), _i]),
+    "wca_collate_plan": (_i, [C.POINTER(_i64), C.POINTER(_i64), _i, C.POINTER(_i64)]),
     "wca_probe_strict_tp": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, C.c_double, _vp]),
     "wca_test_gemm_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _i]),
 }

@@ -252,13 +252,17 @@ inline bool enc_attn_split(const wca_engine* e, int li) { return (e->sites & WCA
 // Operands of one GEMM at a seam. a_pair: the A buffer holds [hi(K) | lo(K)] rows (row stride 2 K); want: the GEMM's site is
 // split. Both: the K-doubled product [A_hi | A_lo] [W | W]^T. A single-precision site behind a pair producer reads the hi halves
 // (hi IS f16(x)); a split site behind a single-precision producer multiplies the f16 rows it got (there is no lo to add).
+// Where launch_gemm takes the persistent 256 x 256 kernel (M, N given), the pair product runs in its SPLITW form: plain W, each W
+// K-tile staged once (a_lo = K); elsewhere as the K-doubled call on the [W | W] copy.
 struct GemmOpnd {
   const half_t* W;
   int lda, K, ldw;
+  long a_lo;
 };
-inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K) {
+inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K, int M = 0, int N = 0, int out_mode = 0) {
   const bool use = a_pair && want;
-  return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K};
+  if (use && M > 0 && gemm_splitw_supported(M, N, K, 2 * K, out_mode)) return GemmOpnd{W1, 2 * K, K, K, (long)K};
+  return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K, 0};
 }
 
 // ---- weight slab layout (two passes: size, then carve)
@@ -460,8 +464,9 @@ int ensure_split_weights(wca_engine* e) {
 
 // c_lo > 0 (split mode, f16 output): the value is stored as the pair hi at C, lo at C + c_lo (out_mode 4)
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
-                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0) {
+                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0, long a_lo = 0) {
   GemmArgs g{};
+  g.a_lo = a_lo;
   g.sk_part = sk_ws;
   g.sk_bytes = sk_bytes;
   g.c_lo = c_lo;
@@ -541,7 +546,7 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
 // as the GEMM's site alone.
 int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, float* x, int M, int N,
                      int K, const float* gamma, const float* beta, half_t* xn, bool ln_pair, int site, bool allow_fused = true, int ev_gemm_site = -1,
-                     int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0) {
+                     int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0, long a_lo = 0) {
   auto ev = [&](int st, int li, int which) {
     if (e->profiling && st >= 0 && li >= 0 && li < 33) {
       (void)hipEventRecord(e->kev[st][li][which], s);
@@ -550,7 +555,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
   };
   ev(ev_gemm_site, ev_gemm_li, 0);
   const int om = ln_pair ? 2 : 1;  // the LayerNorm's consumer is split: xn rows are [hi(N) | lo(N)] (no fused form writes pairs)
-  if (allow_fused && !ln_pair && gemm_ln_supported(M, N, K, e->n_cu)) {
+  if (allow_fused && !ln_pair && a_lo == 0 && gemm_ln_supported(M, N, K, e->n_cu)) {
     GemmArgs g{};
     g.A = A;
     g.lda = lda;
@@ -576,7 +581,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     ev(ev_gemm_site, ev_gemm_li, 1);
     return WCA_OK;
   }
-  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes));
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes, 0, a_lo));
   ev(ev_gemm_site, ev_gemm_li, 1);
   ev(ev_ln_site, ev_ln_li, 0);
   HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s, om * N, ln_pair ? N : 0));
@@ -751,9 +756,9 @@ int run_encoder(wca_engine* e, int B) {
     const LayerW& w2 = e->split ? e->sw.enc[li] : l;  // the K-doubled copies [N][2K] = [W | W] (present while any site is split)
     const int oma = as ? 2 : 1;  // q / k / v rows and the attention output: pairs iff the attention is split
     // q / k / v projection: xn is a pair buffer iff this layer's GEMMs are split (its LayerNorm wrote it for them)
-    const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d);
+    const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d, M, 3 * d, as ? 4 : 0);
     mark(WCA_SITE_QKV, li, 0);
-    HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0));
+    HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0, oq.a_lo));
     mark(WCA_SITE_QKV, li, 1);
     AttnArgs a{};
     a.Q = e->qkv;
@@ -778,20 +783,20 @@ int run_encoder(wca_engine* e, int B) {
     mark(WCA_SITE_ATTN, li, 1);
     // sites OUT / FC2 = the GEMM alone (or the fused GEMM + LayerNorm kernel); the LayerNorm launches: mlp_ln = LN2[li], the next
     // layer's attn_ln / ln_post = LN1[li + 1]
-    const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d);
+    const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d, M, d, 2);
     if (int rc = gemm_residual_ln(e, s, e->att, oo.lda, oo.W, oo.ldw, l.out_b, e->x, M, d, oo.K, l.ln2_g, l.ln2_b, e->xn, gs, 1, e->fuse_ln, WCA_SITE_OUT, li,
-                                  WCA_SITE_LN2, li))
+                                  WCA_SITE_LN2, li, oo.a_lo))
       return rc;
-    const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d);
+    const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d, M, 4 * d, gs ? 4 : 0);
     mark(WCA_SITE_FC1, li, 0);
-    HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0));
+    HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0, o1.a_lo));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
     // the LayerNorm behind fc2 feeds the next layer's q / k / v projection, or (ln_post) the cross-K/V projection
     const bool next_pair = last ? site_on(e, WCA_PSITE_CROSS_KV) : enc_gemm_split(e, li + 1);
-    const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d);
+    const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d, M, d, 2);
     if (int rc = gemm_residual_ln(e, s, e->hid, o2.lda, o2.W, o2.ldw, l.fc2_b, e->x, M, d, o2.K, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
-                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1))
+                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1, o2.a_lo))
       return rc;
   }
   return WCA_OK;
@@ -807,9 +812,9 @@ int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
   const int n_cols = L * 2 * dt - (skip_last_v ? dt : 0);
   const bool ks = site_on(e, WCA_PSITE_CROSS_KV), cs = site_on(e, WCA_PSITE_CAPTURE);
-  const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d);
+  const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d, B * N_CTX, n_cols, cs ? 4 : 0);
   HIPCHK(gemm(e->stream, e->xn, o.lda, o.W, o.ldw, e->kv_b, kvbuf, (cs ? 2 : 1) * L * 2 * dt, B * N_CTX, n_cols, o.K, 0, 0, 3, nullptr, 0,
-              cs ? (long)L * 2 * dt : 0));
+              cs ? (long)L * 2 * dt : 0, o.a_lo));
   return WCA_OK;
 }
 
@@ -834,8 +839,8 @@ int run_decoder_sites(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
   // C = A W^T (+ bias ...): a_pair = the A buffer holds [hi | lo] rows of K values each; c_lo > 0: f16 pair output
   auto mm = [&](const half_t* A, bool a_pair, const half_t* W1, const half_t* W2, const float* bias, void* C, int ldc, int N, int K, int gelu, int out_mode,
                 long c_lo, int site) -> int {
-    const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K);
-    HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo));
+    const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K, M, N, (c_lo > 0 && out_mode == 0) ? 4 : out_mode);
+    HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo, o.a_lo));
     return WCA_OK;
   };
   for (int li = 0; li < L; ++li) {
@@ -2533,6 +2538,21 @@ int wca_comm_destroy(wca_engine* e) {
   return WCA_OK;
 }
 
+int wca_collate_plan(const int64_t* sizes, const int64_t* capacities, int world, int64_t* pad_out) {
+  if (!sizes || !capacities || world < 1) return fail(WCA_ERR_INVALID, "bad argument");
+  int64_t mx = 0, min_cap = capacities[0];
+  for (int i = 0; i < world; ++i) {
+    if (sizes[i] < 0 || capacities[i] < 0) return fail(WCA_ERR_INVALID, "negative size");
+    mx = sizes[i] > mx ? sizes[i] : mx;
+    min_cap = capacities[i] < min_cap ? capacities[i] : min_cap;
+  }
+  if (pad_out) *pad_out = (mx + 15) / 16 * 16;
+  if (mx > min_cap)
+    return fail(WCA_ERR_TOO_LONG, "a rank packed %lld bytes, the smallest gather buffer holds %lld per rank (sizes are in sizes_host: retry)", (long long)mx,
+                (long long)min_cap);
+  return WCA_OK;
+}
+
 int wca_allgather_results(wca_engine* e, const uint8_t* packed_host, int64_t n_bytes, uint8_t* gathered_host, int64_t capacity_per_rank,
                           int64_t* sizes_host) {
   if (!e || !sizes_host || (n_bytes > 0 && !packed_host) || n_bytes < 0 || capacity_per_rank < 0) return fail(WCA_ERR_INVALID, "bad argument");
@@ -2540,21 +2560,26 @@ int wca_allgather_results(wca_engine* e, const uint8_t* packed_host, int64_t n_b
   RcclApi* r = rccl();
   HIPCHK(hipSetDevice(e->device));
   const int W = e->comm_world;
-  // (1) every rank's byte count
-  HIPCHK(e->coll_send.ensure(sizeof(int64_t)));
-  HIPCHK(e->coll_recv.ensure(sizeof(int64_t) * (size_t)W));
-  HIPCHK(hipMemcpyAsync(e->coll_send.p, &n_bytes, sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-  RCCLCHK(r, r->AllGather(e->coll_send.p, e->coll_recv.p, 1, ncclInt64, e->comm, e->stream));
-  HIPCHK(hipMemcpyAsync(sizes_host, e->coll_recv.p, sizeof(int64_t) * (size_t)W, hipMemcpyDeviceToHost, e->stream));
+  // (1) every rank's {byte count, gather capacity}. The capacity is a per-caller argument, so "does it fit" must be decided on
+  // what EVERY rank passed: all ranks then take the same branch and issue the same sequence of collectives
+  const int64_t mine[2] = {n_bytes, capacity_per_rank};
+  std::vector<int64_t> pairs(2 * (size_t)W), caps((size_t)W);
+  HIPCHK(e->coll_send.ensure(sizeof(mine)));
+  HIPCHK(e->coll_recv.ensure(sizeof(mine) * (size_t)W));
+  HIPCHK(hipMemcpyAsync(e->coll_send.p, mine, sizeof(mine), hipMemcpyHostToDevice, e->stream));
+  RCCLCHK(r, r->AllGather(e->coll_send.p, e->coll_recv.p, 2, ncclInt64, e->comm, e->stream));
+  HIPCHK(hipMemcpyAsync(pairs.data(), e->coll_recv.p, sizeof(mine) * (size_t)W, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(hipStreamSynchronize(e->stream));
-  int64_t mx = 0;
-  for (int i = 0; i < W; ++i) mx = sizes_host[i] > mx ? sizes_host[i] : mx;
-  // every rank takes the same branch: the sizes are identical everywhere
-  if (mx > capacity_per_rank) return fail(WCA_ERR_TOO_LONG, "a rank packed %lld bytes, the gather buffer holds %lld per rank (sizes are in sizes_host: retry)", (long long)mx, (long long)capacity_per_rank);
-  if (mx == 0) return WCA_OK;
+  for (int i = 0; i < W; ++i) {
+    sizes_host[i] = pairs[2 * i];
+    caps[i] = pairs[2 * i + 1];
+  }
+  int64_t pad64 = 0;
+  if (int rc = wca_collate_plan(sizes_host, caps.data(), W, &pad64)) return rc;  // identical inputs on every rank: identical verdict
+  if (pad64 == 0) return WCA_OK;
   if (!gathered_host) return fail(WCA_ERR_INVALID, "null gather buffer");
   // (2) the packed records, padded to the largest count
-  const size_t pad = (size_t)((mx + 15) / 16 * 16);
+  const size_t pad = (size_t)pad64;
   HIPCHK(e->coll_send.ensure(pad));
   HIPCHK(e->coll_recv.ensure(pad * (size_t)W));
   HIPCHK(hipMemsetAsync(e->coll_send.p, 0, pad, e->stream));
@@ -2606,6 +2631,35 @@ int wca_test_gemm(wca_engine* e, const void* a, const void* w, const float* bias
   g.supertile = out_mode >> 20;             // 0 = launch_gemm's choice (tools: tile-order experiments)
   g.sk_part = e->sk_big[0];                  // few tiles, K >= 2048, out_mode 2: split-K with the engine's workspace, as the encoder does
   g.sk_bytes = e->sk_big_bytes;
+  HIPCHK(launch_gemm(g, e->stream));
+  return WCA_OK;
+}
+
+int wca_test_gemm_pairs(wca_engine* e, const void* a2, const void* w, const float* bias, void* c, int M, int N, int K, int gelu, int out_mode) {
+  if (!e || !a2 || !w || !c) return fail(WCA_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(e->device));
+  const int om = out_mode & 0xff;
+  if (!gemm_splitw_supported(M, N, K, 2 * K, om)) return fail(WCA_ERR_INVALID, "the pair-operand kernel does not take M=%d N=%d K=%d out_mode %d", M, N, K, om);
+  GemmArgs g{};
+  g.A = (const half_t*)a2;
+  g.lda = 2 * K;
+  g.a_lo = K;
+  g.W = (const half_t*)w;
+  g.ldw = K;
+  g.bias = bias;
+  g.C = c;
+  g.ldc = N;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.gelu = gelu;
+  g.out_mode = om;
+  if (om == 4) {
+    g.ldc = 2 * N;
+    g.c_lo = N;
+  }
+  g.force_tile = (out_mode >> 8) & 0xfff;
+  g.site = 1;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }

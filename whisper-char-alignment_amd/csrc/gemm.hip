@@ -408,7 +408,16 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmArgs a) {
 // request i covers tile rows i*64 + w*8 .. +7, so ONE per-lane byte offset per operand suffices.
 // The tile's 256 bias values arrive in LDS by DMA with its first operands: a global load inside the epilogue would
 // have to wait (vmcnt is one in-order counter) for the next tile's operand DMA issued just before it.
-template <int OUT_MODE, bool GELU, int SITE, bool STAMP = false>
+// SPLITW (reference-precision operands, A rows = [hi(K) | lo(K)], a.a_lo = K, W the PLAIN [N][K] matrix): the K loop walks
+// (k tile 0: hi, lo), (k tile 1: hi, lo), ... -- two steps per W K-tile. The W tile is fetched ONCE (on even steps, into its own
+// ring of two slots) and its register fragments are re-used by the odd step: per algorithmic K tile 3 tiles of DMA and 40 fragment
+// reads per wave instead of the 4 tiles / 48 reads of the K-doubled call [A_hi | A_lo] [W | W]^T, and no second copy of W.
+template <int V>
+struct GemmIntC {
+  static constexpr int value = V;
+};
+
+template <int OUT_MODE, bool GELU, int SITE, bool STAMP = false, bool SPLITW = false>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -452,9 +461,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 
   // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each.
   // ta / tw: byte offset of (tile row 0, K offset) in A / W.
-  auto stage_one = [&](int buf, unsigned ta, unsigned tw, int g) {
+  auto stage_one = [&](int buf, int bufw, unsigned ta, unsigned tw, int g) {
     half_t* At = lds + buf * (2 * TILE256);
-    half_t* Wt = At + TILE256;
+    half_t* Wt = lds + bufw * (2 * TILE256) + TILE256;
     const int i = g >> 1;
     // the wave-uniform part stays an opaque SGPR value: one v_add per request instead of eight per-lane
     // induction variables (the loop strength reduction otherwise keeps va + i*sa64 + k in 8 VGPRs and spills)
@@ -488,7 +497,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     _Pragma("unroll") for (int t = 0; t < 8; ++t) XF[t] = *reinterpret_cast<const half8*>((AT) + (XB) + t * 1024); \
   } while (0)
 
-  const int nk = a.K / BK;
+  const int nk = SPLITW ? 2 * (a.K / BK) : a.K / BK;   // K steps of one tile
+  // byte offset of K step s inside an A row / a W row
+  auto a_koff = [&](int s_) -> unsigned { return SPLITW ? (unsigned)(((s_ & 1) * (int)a.a_lo + (s_ >> 1) * BK) * 2) : (unsigned)(s_ * (BK * 2)); };
+  auto w_koff = [&](int s_) -> unsigned { return SPLITW ? (unsigned)((s_ >> 1) * (BK * 2)) : (unsigned)(s_ * (BK * 2)); };
   // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
   //  fetch/MFMA orders or different DMA-issue windows to break SIMD-partner lockstep; a software L2 prefetch
   //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %);
@@ -554,11 +566,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   int par = 0;  // bias buffer of the current tile
   stage_bias(0, n0);
 #pragma unroll
-  for (int g = 0; g < 8; ++g) stage_one(0, ta, tw, g);
+  for (int g = 0; g < 8; ++g) stage_one(0, 0, ta, tw, g);
   if (nk > 1) {
 #pragma unroll
-    for (int g = 0; g < 8; ++g) stage_one(1, ta + BK * 2, tw + BK * 2, g);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    for (int g = 0; g < 8; ++g)
+      if (!SPLITW || (g & 1) == 0) stage_one(1, 1, ta + a_koff(1), tw + w_koff(1), g);  // SPLITW: step 1 multiplies the W tile of step 0
+    if (SPLITW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -595,10 +609,17 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     }
     const int m0n = tmn_ * 256, n0n = tnn_ * 256;
     const unsigned tan = (unsigned)m0n * a.lda * 2u, twn = (unsigned)n0n * a.ldw * 2u;
-    for (int kt = 0; kt < nk; ++kt) {
-      const int cur = kt & 1;
+    // one K step; PAR >= 0: the step's parity (= its A ring slot) is a compile-time constant (SPLITW: even = first use of a W tile)
+    auto kstep = [&](auto par_c, const int kt) {
+      constexpr int PAR = decltype(par_c)::value;
+      const int cur = PAR >= 0 ? PAR : (kt & 1);
+      const int wslot = SPLITW ? ((kt >> 1) & 1) : cur;                 // W ring slot of this step
+      const int wslot_n = SPLITW ? (((kt + 1) >> 1) & 1) : (cur ^ 1);   // ... of step kt + 1
+      // this step's W fragments are new (SPLITW, odd step: those of the step before); wave-uniform
+      const bool W_FRESH = !SPLITW || (PAR >= 0 ? PAR == 0 : (kt & 1) == 0);
+      const bool W_NEXT_FRESH = !SPLITW || (PAR >= 0 ? PAR == 1 : (kt & 1) == 1);
       const half_t* At = lds + cur * (2 * TILE256);
-      const half_t* Wt = At + TILE256;
+      const half_t* Wt = lds + wslot * (2 * TILE256) + TILE256;
       WCA_STAMP(0);
       // ---- K half 0 (fragments w0/x0 were fetched under the previous step's half 1). The 12 fragment reads of
       // half 1 are issued two at a time between groups of 4 MFMAs.
@@ -610,8 +631,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (g < 2) {
-          w1[2 * g] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g) * 1024);
-          w1[2 * g + 1] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g + 1) * 1024);
+          if (W_FRESH) {
+            w1[2 * g] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g) * 1024);
+            w1[2 * g + 1] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g + 1) * 1024);
+          }
         } else if (g < 6) {
           x1[2 * (g - 2)] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2)) * 1024);
           x1[2 * (g - 2) + 1] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2) + 1) * 1024);
@@ -629,12 +652,15 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       // half-0 fragments are fetched (within a tile), ONE DMA request and up to two ds_reads per group of 4 MFMAs: 64 back-to-back
       // requests per CU right after the barrier serialise in the memory pipe and delay the MFMAs of the waves that
       // issue last (measured with s_memtime stamps: ~1000 cycles of barrier skew per K tile).
+      // SPLITW: the W tile of step s+2 is new only when s is even (it goes to the W slot that step s-1 read last: every wave is
+      // past that step's barrier), and the next step's W fragments are re-fetched only when s is odd.
       const bool in_tile2 = kt + 2 < nk;
       const bool more1 = kt + 1 < nk, more2 = in_tile2 || has_next;
-      const unsigned ka = (in_tile2 ? ta + (unsigned)(kt + 2) * (BK * 2) : tan + (unsigned)(kt + 2 - nk) * (BK * 2));
-      const unsigned kw = (in_tile2 ? tw + (unsigned)(kt + 2) * (BK * 2) : twn + (unsigned)(kt + 2 - nk) * (BK * 2));
+      const unsigned ka = (in_tile2 ? ta + a_koff(kt + 2) : tan + a_koff(kt + 2 - nk));
+      const unsigned kw = (in_tile2 ? tw + w_koff(kt + 2) : twn + w_koff(kt + 2 - nk));
+      const int wslot_2 = SPLITW ? (wslot ^ 1) : cur;   // W ring slot of step kt + 2
       const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
-      const half_t* Wn = An + TILE256;
+      const half_t* Wn = lds + wslot_n * (2 * TILE256) + TILE256;
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         __builtin_amdgcn_s_setprio(1);
@@ -642,11 +668,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more2) stage_one(cur, ka, kw, g);
+        if (more2 && (W_FRESH || (g & 1) == 0)) stage_one(cur, wslot_2, ka, kw, g);
         if (more1) {
           if (g < 2) {
-            w0[2 * g] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g) * 1024);
-            w0[2 * g + 1] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g + 1) * 1024);
+            if (W_NEXT_FRESH) {
+              w0[2 * g] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g) * 1024);
+              w0[2 * g + 1] = *reinterpret_cast<const half8*>(Wn + wb0 + (2 * g + 1) * 1024);
+            }
           } else if (g < 6) {
             x0[2 * (g - 2)] = *reinterpret_cast<const half8*>(An + xb0 + (2 * (g - 2)) * 1024);
             x0[2 * (g - 2) + 1] = *reinterpret_cast<const half8*>(An + xb0 + (2 * (g - 2) + 1) * 1024);
@@ -655,7 +683,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(4);
-    }
+    };
+    // (SPLITW with the step parity as a compile-time constant -- the loop unrolled by two -- spills 70-90 VGPRs: both steps' LDS
+    //  base addresses stay live; the runtime parity costs two scalar branches per step)
+    for (int kt = 0; kt < nk; ++kt) kstep(GemmIntC<-1>{}, kt);
 
     if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
       a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 0] = __builtin_readcyclecounter();
@@ -811,6 +842,15 @@ bool gemm_ln_supported(int M, int N, int K, int n_cu) {
                                        // workgroups of an XCD label holds at least one whole panel (N / 256 tiles)
 }
 
+bool gemm_splitw_supported(int M, int N, int K, int lda, int out_mode) {
+  if (M < 1 || N < 1 || K < 128 || (K % 128) != 0) return false;   // whole pairs of K tiles: the W ring's slot parity carries over a tile boundary
+  if (out_mode != 0 && out_mode != 1 && out_mode != 2 && out_mode != 4) return false;
+  const long tiles256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+  if (tiles256 < 192) return false;                                 // launch_gemm sends fewer tiles to the 128 x 128 kernel
+  const size_t a_need = ((size_t)(M - 1) * lda + 2 * (size_t)K) * sizeof(half_t), w_need = ((size_t)(N - 1) * K + K) * sizeof(half_t);
+  return a_need < 0x7fffffffull && w_need < 0x7fffffffull;          // buffer-descriptor ranges
+}
+
 hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
@@ -818,7 +858,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
   // M <= 64 (greedy-decode steps): weight-streaming skinny kernel; force_tile 64 forces it, 128 etc. bypass it
   if (a.out_mode == 4 && (a.c_lo <= 0 || (a.c_lo & 7))) return hipErrorInvalidValue;
-  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.out_mode != 4) {
+  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.out_mode != 4 && a.a_lo <= 0) {
     const dim3 sgrid((unsigned)((a.N + 15) / 16)), sblock(256);
 #define WCA_LAUNCH_SK(OM, G) hipLaunchKernelGGL((gemm_skinny_f16_kernel<OM, G>), sgrid, sblock, 0, s, a)
     if (a.out_mode == 0) {
@@ -836,7 +876,11 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if (a.force_tile == 64) return hipErrorInvalidValue;
   // tile choice: the 256^2 kernel runs one workgroup per CU, so it needs about a full wave of 256 workgroups
   const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
-  const size_t a_need = ((size_t)(a.M - 1) * a.lda + a.K) * sizeof(half_t), w_need = ((size_t)(a.N - 1) * a.ldw + a.K) * sizeof(half_t);
+  const bool splitw = a.a_lo > 0;
+  if (splitw && (a.force_tile == 64 || a.force_tile == 128 || a.force_tile == 256 || a.a_rows_per_batch != 0 || a.dbg != nullptr ||
+                 !gemm_splitw_supported(a.M, a.N, a.K, a.lda, a.out_mode) || (a.a_lo & 7) != 0))
+    return hipErrorInvalidValue;
+  const size_t a_need = ((size_t)(a.M - 1) * a.lda + (splitw ? (size_t)a.a_lo : 0) + a.K) * sizeof(half_t), w_need = ((size_t)(a.N - 1) * a.ldw + a.K) * sizeof(half_t);
   const bool can_buf = a.a_rows_per_batch == 0 && a_need < 0x7fffffffull && w_need < 0x7fffffffull;
   if (a.a_bytes == 0) a.a_bytes = (unsigned)a_need;
   if (a.w_bytes == 0) a.w_bytes = (unsigned)w_need;
@@ -866,10 +910,10 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       shmem += 2 * 256 * sizeof(float);  // the tile's bias values, double buffered
       // persistent: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... (the ring-slot parity carries
       // over a tile boundary only for an even number of K tiles); force_tile 258 = one tile per workgroup
-      const int nk = a.K / BK;
+      const int nk = (splitw ? 2 : 1) * (a.K / BK);
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
       // (K <= 2048 since round 3: the K-doubled QKV / fc1 of the split mode measure -5 % / -3 % with the supertile order, same-box A/B)
-      if (a.supertile <= 0) a.supertile = (a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1;
+      if (a.supertile <= 0) a.supertile = ((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1;
     }
   } else {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
@@ -909,9 +953,21 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (e != hipSuccess) return e;                                                                \
     hipLaunchKernelGGL((KERN<OM, G, S, ST>), grid, block, shmem, s, a);                           \
   } while (0)
+#define WCA_LAUNCH_K5(KERN, OM, G, S)                                                              \
+  do {                                                                                              \
+    static std::atomic<unsigned> attr_mask5{0};                                                     \
+    if (!(attr_mask5.load(std::memory_order_acquire) & (1u << (dev & 31)))) {                       \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, false, true>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
+      if (e != hipSuccess) return e;                                                                \
+      attr_mask5.fetch_or(1u << (dev & 31), std::memory_order_release);                             \
+    }                                                                                               \
+    hipLaunchKernelGGL((KERN<OM, G, S, false, true>), grid, block, shmem, s, a);                    \
+  } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (pipelined && a.dbg) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, S, true); \
+    if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 4); else if ((S) == 3) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 3); else WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 1); } \
+    else if (pipelined && a.dbg) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, S, true); \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
@@ -958,6 +1014,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
 #undef WCA_LAUNCH_K4
+#undef WCA_LAUNCH_K5
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

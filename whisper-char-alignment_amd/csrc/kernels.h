@@ -13,6 +13,9 @@ typedef _Float16 half_t;
 // base + b * batch_stride + t * ld  (this is how the conv stem reads overlapping windows).
 struct GemmArgs {
   const half_t* A;
+  long a_lo;               // > 0: A rows are [hi(K) | lo(K)] pairs, lo half a_lo elements after the hi half, and W is the PLAIN [N][K]
+                           // matrix: C = (A_hi + A_lo) W^T with each W K-tile staged once (gemm256p SPLITW; only where
+                           // gemm_splitw_supported() says so -- elsewhere the caller passes K-doubled operands [A_hi | A_lo], [W | W])
   int lda;                 // elements between consecutive A rows inside a batch
   int a_rows_per_batch;    // 0 => flat
   long a_batch_stride;     // elements
@@ -71,6 +74,8 @@ int gemm_rows_pick_splitk(int K);
 size_t gemm_rows_workspace_bytes(int M, int N, int splitk);
 // out_mode 3 (residual + LayerNorm epilogue) is available for this shape on a device with n_cu compute units
 bool gemm_ln_supported(int M, int N, int K, int n_cu);
+// the pair-operand form (GemmArgs.a_lo > 0, plain W) is available for this flat-A problem (launch_gemm picks the persistent 256 x 256 kernel)
+bool gemm_splitw_supported(int M, int N, int K, int lda, int out_mode);
 
 // ---------------------------------------------------------------- attention (attention.hip)
 // Flash-style multi-head attention with head_dim == 64 (every Whisper size).

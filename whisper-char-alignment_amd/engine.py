@@ -435,8 +435,8 @@ class WhisperAMD:
         while True:
             out = np.zeros((world, cap), dtype=np.uint8)
             rc = self._lib.wca_allgather_results(self._h, packed.ctypes.data_as(C.c_void_p), int(packed.size), out.ctypes.data_as(C.c_void_p), cap, sizes)
-            if rc == _lib.ERR_TOO_LONG:   # some rank packed more than `cap` bytes (every rank sees the same sizes): retry with room
-                cap = max(int(v) for v in sizes)
+            if rc == _lib.ERR_TOO_LONG:   # some rank packed more than the smallest `cap` of any rank: EVERY rank gets this verdict
+                cap = max(int(v) for v in sizes)   # (decided on the gathered {size, capacity} pairs), and retries with the same room
                 continue
             _lib.check(rc)
             return [out[r, :int(sizes[r])].copy() for r in range(world)]
