@@ -84,7 +84,7 @@ def test_split_gemm_is_fp32_accurate(eng, lib, wca, M, N, K, tile):
     assert herr > 20 * err, (herr, err)
 
 
-@pytest.mark.parametrize("M,N,K,tile", [(6144, 2048, 128, 0), (6100, 2100, 256, 0), (24000, 1024, 1024, 0), (24000, 1024, 1024, 258), (12000, 1024, 4096, 0),
+@pytest.mark.parametrize("M,N,K,tile", [(6144, 2048, 128, 0), (6100, 2100, 256, 0), (24000, 1024, 1024, 0), (24000, 1024, 1024, 258), (12288, 1024, 4096, 0),
                                         (24064, 3072, 1024, 0)])
 def test_pair_gemm_w_tile_staged_once(eng, lib, wca, M, N, K, tile):
     """The persistent 256 x 256 kernel in its SPLITW form -- A rows [hi | lo], the PLAIN W, every W K-tile staged once and its

@@ -106,7 +106,13 @@ __global__ __launch_bounds__(256) void logmel_power_kernel(LogMelArgs a) {
     const int lo = a.filt_lo[m], hi = a.filt_hi[m];
     const float* fr = a.filters + (long)m * NBIN;
     float acc = 0.f;
-    for (int k = lo; k < hi; ++k) acc = fmaf(fr[k], s_pow[k], acc);
+    if (a.precise) {  // the reference's `filters @ magnitudes` is an f32 matmul in some blocked order: the f64 sum is within half an ulp of any
+      double acc64 = 0.0;
+      for (int k = lo; k < hi; ++k) acc64 = fma((double)fr[k], (double)s_pow[k], acc64);
+      acc = (float)acc64;
+    } else {
+      for (int k = lo; k < hi; ++k) acc = fmaf(fr[k], s_pow[k], acc);
+    }
     lv = log10f(fmaxf(acc, 1e-10f));
     a.scratch[((long)b * a.n_mels + m) * NFRAMES + t] = lv;
   }

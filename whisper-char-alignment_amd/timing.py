@@ -21,10 +21,6 @@ _pf = C.POINTER(C.c_float)
 _pi = C.POINTER(C.c_int32)
 
 
-def _register_engine(model):
-    pass  # engines register themselves at construction (engine._registry)
-
-
 def _engine_for(device):
     """An engine on `device` for the ops that need no weights (filter_attention / force_align / dtw)."""
     from .engine import default_engine
@@ -45,7 +41,6 @@ def get_attentions(mel, tokens, model, tokenizer, max_frames, medfilt_width=7, q
     """Teacher-forced forward with every cross-attention head's QK logits captured, sliced to
     `max_frames`, median filtered, scaled and softmaxed (timing.py:45-67).
     mel (n_mels, 3000) f32, tokens 1-D int64 -> weights (L, H, n, F) f32 on the GPU, logits (n, V) f32."""
-    _register_engine(model)
     max_frames = int(max_frames)
     weights, logits = model.get_attentions(mel.unsqueeze(0), tokens.unsqueeze(0), [max_frames], medfilt_width, qk_scale)
     return weights[0], logits[0]
