@@ -214,80 +214,107 @@ def test_layernorm_epilogue_fusion_equals_separate_launches(wca):
     del model
 
 
-def test_north_star_config_parity_medium_dims(wca):
-    """The headline configuration at the bench's DEFAULT precision (f16 operands) and batch size: whisper-medium dimensions, PEAKY
-    seeded weights (cross_qk_std=0.08: sharp maps, so f16 operand rounding can move heads / boundaries), 10 s audio, 64-char text,
-    topk=10, medfilt 3, through the FUSED wca_align_batch at B = 64 (persistent GEMMs, batched attention grid, batched DTW exactly
-    as timed by bench.py). The batch holds ids 100-131 AND the bench's own ids 10000-10031 (which contain known misses of this
-    mode); 48 of them (100-123, 10000-10023) are also aligned by the fp32 CPU oracle. The gate cannot pass by choice of ids: the ACCEPTANCE SET is defined on the
-    oracle alone, before looking at the GPU result --
-      (a) the oracle's 10th and 11th head scores are further apart than 2e-3 relative (the measured f16 score deviation is
-          6e-4 ... 1.6e-3, profiles/r02_parity_probe.txt), and
-      (b) the oracle's own DTW path stays within one frame when its aggregated matrix is perturbed by 3e-3 relative noise (32
-          seeded trials; the measured f16 matrix deviation is 1.7e-3) --
-    and on that set EVERY word boundary must be within one 20 ms frame and every selected head must be the oracle's up to score
-    noise. Utterances outside the set are decided by rounding in any reduced-precision forward: they are counted and printed, and
-    they are exactly what the reference-precision mode is for (tests/test_split_gpu.py holds them to the same bar with no exceptions)."""
-    import sys
-    from oracle import timing_ref, whisper_ref, tokenizer_ref
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    import bench
+GATE_IDS = list(range(100, 132)) + list(range(10000, 10032))
+
+
+def _gate_batch(wca):
     syn, tk, rt, tm, audio = _mods()
     dims = wca.dims_for("medium")
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
     B = 64
-    ids = list(range(100, 132)) + list(range(10000, 10032))
     model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
-    ref = whisper_ref.WhisperRef(sd, dims)
-    tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    utts = [_utt(syn, rt, tok, u, 160000, 64) for u in ids]
+    tok = tk.get_tokenizer(True, language="English")
+    utts = [_utt(syn, rt, tok, u, 160000, 64) for u in GATE_IDS]
     assert all(len(u[3]) == 69 for u in utts)
-    pcm = np.stack([u[0] for u in utts])
-    tarr = np.asarray([u[3] for u in utts], dtype=np.int64)
+    pcm = torch.from_numpy(np.stack([u[0] for u in utts])).cuda()
+    tarr = torch.from_numpy(np.asarray([u[3] for u in utts], dtype=np.int64)).cuda()
     opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
-    jump, sel = model.align_batch(torch.from_numpy(pcm).cuda(), [160000] * B, torch.from_numpy(tarr).cuda(), [69] * B, [500] * B, opts)
-    H, LH = dims.n_text_head, dims.n_text_layer * dims.n_text_head
-    total = ident = n_accept = 0
-    offenders, outside_set, head_match = [], [], 0
-    checked = [i for i, uid in enumerate(ids) if uid < 124 or 10000 <= uid < 10024]   # 48 of the 64 (the oracle is ~2 s per utterance)
-    for i in checked:
-        uid = ids[i]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_word_times_medium_peaky.npz"))
+    return dims, sd, model, tok, utts, (pcm, [160000] * B, tarr, [69] * B, [500] * B, opts), gold
+
+
+def _boundary_stats(tm, tok, utts, jump, gold):
+    total = within = ident = 0
+    offenders = []
+    for i, uid in enumerate(GATE_IDS):
+        _p, _text, tt, _tokens = utts[i]
+        _w, st, en = tm.words_from_jump_frames(jump[i], tt, tok, "char")
+        off = 0
+        for a, b in ((np.asarray(st), gold["st_%d" % uid]), (np.asarray(en), gold["en_%d" % uid])):
+            assert len(a) == len(b), uid
+            total += len(a)
+            within += int(np.sum(np.abs(a - b) <= 0.02 + 1e-9))
+            ident += int(np.sum(a == b))
+            off += int(np.sum(np.abs(a - b) > 0.02 + 1e-9))
+        if off:
+            offenders.append((uid, off))
+    return total, within, ident, offenders
+
+
+def test_contract_mode_parity_no_exclusions(wca):
+    """THE GATE of the contract line (north_star: word start / end times within one 20 ms encoder frame of the reference CPU path on
+    the same audio + text). The headline configuration -- whisper-medium dimensions, PEAKY seeded weights (cross_qk_std = 0.08), 10 s
+    audio, 64-char text, topk 10, medfilt 3 -- through the FUSED wca_align_batch at B = 64 in the engine's REFERENCE precision mode
+    (wca_set_precision(WCA_PRECISION_REFERENCE), what bench.py's `value` runs), on ids 100-131 + the bench's own ids 10000-10031,
+    which include utterances whose oracle head scores are tied to 4e-6 / 3e-4 and every known miss of the f16 mode. EVERY boundary
+    of EVERY utterance must be within one frame of the fp32 CPU oracle's: no acceptance set, no excused utterance.
+    The oracle's word times come from tests/golden/oracle_word_times_medium_peaky.npz (tests/golden/make_oracle_word_times.py);
+    the LIVE oracle is run on three of the utterances and must reproduce the fixture, and the step-by-step API's scores / matrix on
+    one of them are compared with the live oracle's."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok, utts, args, gold = _gate_batch(wca)
+    model.set_precision("reference")
+    assert model.precision == "reference" and model.precision_sites == (["enc_gemm", "enc_attn", "cross_kv", "dec", "capture"], 0)
+    jump, sel = model.align_batch(*args)
+    total, within, ident, offenders = _boundary_stats(tm, tok, utts, jump, gold)
+    print("contract mode, medium B=64 fused: %d boundaries over %d utterances, within one frame %d, identical %d, offenders %s"
+          % (total, len(GATE_IDS), within, ident, offenders))
+    assert total > 1200 and within == total and not offenders, offenders
+    # head selection: the oracle's top-10, or heads whose oracle score is within fp32 noise (1e-5 relative) of its 10th best
+    H = dims.n_text_head
+    for i, uid in enumerate(GATE_IDS):
+        sc = gold["sc_%d" % uid].astype(np.float64)
+        kth = np.sort(sc)[-10]
+        assert all(sc[int(h)] >= kth - 1e-5 * abs(kth) for h in sel[i][:10]), uid
+    # the live oracle reproduces the fixture (and the engine's scores / matrix agree with it to fp32 noise)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    rtok = tokenizer_ref.CharTokenizer()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    for i in (0, 33, 40):   # ids 100, 10001, 10008
+        uid = GATE_IDS[i]
         p, text, tt, tokens = utts[i]
         mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(p)), audio.mel_filters(80))
         rw, _ = timing_ref.get_attentions(mel, torch.tensor(tokens), ref, 500, 3, 1.0)
         rwords, rst, ren, rmatrix, rscores = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
-        allref = {lh: s_ for s_, lh, _ in timing_ref.filter_attention(rw, LH)[1]}
-        ranked = sorted(allref.values())
-        gap = (ranked[-10] - ranked[-11]) / abs(ranked[-10])
-        accepted = gap > 2e-3 and not bench.oracle_is_ill_conditioned(rmatrix, list(tt), np.asarray(rst), np.asarray(ren), eps=3e-3, trials=32)
-        n_accept += int(accepted)
-        words, st, en = tm.words_from_jump_frames(jump[i], tt, tok, "char")
-        assert words == rwords
-        n_off = 0
-        for a, b, kind in ((st, rst, "start"), (en, ren, "end")):
-            d = np.abs(np.asarray(a) - np.asarray(b))
-            n_off += int((d > 0.02 + 1e-9).sum())
-            if accepted:
-                total += len(a)
-                ident += int((np.asarray(a) == np.asarray(b)).sum())
-                offenders += [(uid, kind, int(j), float(a[j]), float(b[j])) for j in np.nonzero(d > 0.02 + 1e-9)[0]]
-        if not accepted:
-            outside_set.append((uid, "gap %.1e" % gap, n_off))
-            continue
-        # head selection: each GPU-selected head must score (in the fp32 oracle) at least the oracle's 10th best minus the
-        # f16-forward noise on a score (~1e-3 relative)
-        kth = rscores[0][0]
-        for hd in sel[i]:
-            assert allref[(int(hd) // H, int(hd) % H)] >= kth - 2e-3 * abs(kth), (uid, int(hd), kth)
-        head_match += len(set(int(h) for h in sel[i]) & set(l * H + h for _, (l, h), _ in rscores))
-    print("medium B=64 fused, f16 mode: acceptance set %d of %d utterances; on it %d boundaries, identical %d, outside one frame %d, top-10 heads "
-          "shared %d/%d; outside the set (oracle near-tied or ill-conditioned; boundaries off): %s"
-          % (n_accept, len(checked), total, ident, len(offenders), head_match, 10 * n_accept, outside_set))
-    assert n_accept >= 30, n_accept            # the criterion is not a blanket excuse (measured: 49 of 64 at this threshold; 48 are checked)
-    assert not offenders, offenders
-    # step-by-step API at B = 1 on one utterance: maps and logits against the oracle (operand rounding visible here)
+        assert np.array_equal(np.asarray(rst), gold["st_%d" % uid]) and np.array_equal(np.asarray(ren), gold["en_%d" % uid]), uid
+        if i == 0:
+            w, _ = tm.get_attentions(mel.cuda(), torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
+            _wd, st, en, matrix, scores = tm.force_align(w, tt, tok, "char", "topk", topk=10)
+            assert [lh for _, lh, _ in scores] == [lh for _, lh, _ in rscores]
+            assert max(abs(a[0] - b[0]) / abs(b[0]) for a, b in zip(scores, rscores)) < 1e-5
+            assert ((matrix.cpu() - rmatrix).norm() / rmatrix.norm()).item() < 2e-5
+            assert (w.cpu() - rw).abs().max().item() < 5e-6
+    del model
+
+
+def test_f16_operating_point_medium_dims(wca):
+    """The f16-operand fast mode (the engine's construction default, `f16_operating_point` in the bench line) on the same batch:
+    NOT the contract line -- operand rounding moves a few near-tied head selections / ill-conditioned paths (measured on the
+    301-utterance leg: 98.5 % of the boundaries within one frame, 292 of 301 utterances clean, profiles/r04_precision_ablation.txt).
+    Held to a statistical bar against the same oracle fixture, plus the step-by-step API's maps / logits against the live oracle."""
+    from oracle import timing_ref, whisper_ref
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok, utts, args, gold = _gate_batch(wca)
+    assert model.precision == "f16"
+    jump, sel = model.align_batch(*args)
+    total, within, ident, offenders = _boundary_stats(tm, tok, utts, jump, gold)
+    print("f16 mode, medium B=64 fused: %d boundaries, within one frame %d, identical %d, utterances with a boundary off: %s" % (total, within, ident, offenders))
+    assert within >= 0.96 * total, (within, total)
+    assert len(offenders) <= 6, offenders
     p, text, tt, tokens = utts[0]
+    ref = whisper_ref.WhisperRef(sd, dims)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
     mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(p)), 80, model=model)
     w, logits = tm.get_attentions(mel, torch.tensor(tokens).cuda(), model, tok, 500, medfilt_width=3)
     rw, rlogits = timing_ref.get_attentions(mel.cpu(), torch.tensor(tokens), ref, 500, 3, 1.0)

@@ -399,3 +399,38 @@ def test_dtw_and_median_vs_hf_ports():
     for shape, w in (((2, 3, 11, 50), 7), ((1, 2, 5, 9), 3), ((1, 1, 4, 3), 7), ((3, 2, 6, 64), 1), ((1, 1, 2, 4), 9)):
         a = torch.from_numpy(rng.standard_normal(shape).astype(np.float32))
         assert torch.equal(timing_ref.median_filter(a, w), _median_filter(a, w)), (shape, w)
+
+
+def test_oracle_word_time_fixture_is_reproduced_by_the_live_oracle():
+    """tests/golden/oracle_word_times_medium_peaky.npz (the word times the GPU contract gate compares with) is what oracle/ computes:
+    structure of all 333 entries, and the LIVE oracle at whisper-medium dimensions on one utterance (id 101) reproduces its word
+    times exactly and its 384 head scores to fp32 noise."""
+    import importlib
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    wca = importlib.import_module("whisper-char-alignment_amd")
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_word_times_medium_peaky.npz"))
+    ids = list(range(100, 132)) + list(range(10000, 10301))
+    assert len(gold.files) == 3 * len(ids)
+    for u in ids:
+        st, en, sc = gold["st_%d" % u], gold["en_%d" % u], gold["sc_%d" % u]
+        assert len(st) == len(en) >= 2 and sc.shape == (384,) and np.all(np.isfinite(sc))
+        assert np.all(np.diff(en) >= 0) and np.all(st[1:] == en[:-1]) and 0 <= st[0] and en[-1] <= 10.0
+        assert len(st) == len(syn.synth_text(u, 64).split())   # one (start, end) per word; the <|endoftext|> pseudo-word has none (timing.py:105-113)
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    ref = whisper_ref.WhisperRef(sd, dims)
+    tok = tokenizer_ref.CharTokenizer()
+    u = 101
+    mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(syn.synth_audio(u, 160000))), audio.mel_filters(80))
+    tt = tokenizer_ref.encode_char(syn.synth_text(u, 64), tok)
+    tokens = torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot])
+    w, _ = timing_ref.get_attentions(mel, tokens, ref, 500, 3, 1.0)
+    _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", 10)
+    assert np.array_equal(np.asarray(st), gold["st_%d" % u]) and np.array_equal(np.asarray(en), gold["en_%d" % u])
+    _sel, all_scores = timing_ref.filter_attention(w, 384, 1, 1, 0)
+    live = np.zeros(384)
+    for s_, (l, h), _n in all_scores:
+        live[l * 16 + h] = s_
+    assert np.max(np.abs(live - gold["sc_%d" % u]) / np.abs(live)) < 1e-5

@@ -227,7 +227,13 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
         for (int r = 0; r < 4; ++r) m = fmaxf(m, st[s][t][r]);
       mx[s] = xor32_maxf(xor16_maxf(m));
     }
-    if (__any((mx[0] > m_run[0]) || (mx[1] > m_run[1]))) {  // wave-uniform: some row's running maximum grows
+    // DEFERRED running maximum (as in attention.hip): the reference point of a row is raised only when the tile maximum exceeds it
+    // by more than 8 in the log2 domain (p <= 2^8: nowhere near the range of the f16 hi half, and p is carried as a pair anyway), or
+    // when the first finite score of a row arrives. On random data SOME row of a wave grows its maximum in almost every tile, so the
+    // undeferred branch (2 exp2 + 34 multiplies per lane) ran on nearly all of them.
+    const float thr_raw = 8.0f / c_log2;
+    if (__any((mx[0] > m_run[0] + thr_raw) || (mx[1] > m_run[1] + thr_raw) || (m_run[0] == -INFINITY && mx[0] != -INFINITY) ||
+              (m_run[1] == -INFINITY && mx[1] != -INFINITY))) {  // wave-uniform
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float m_new = fmaxf(m_run[s], mx[s]);

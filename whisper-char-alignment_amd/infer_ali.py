@@ -151,7 +151,7 @@ def infer_dataset(args, model=None):
     if args.batch_size > model.max_batch:
         raise SystemExit("--batch_size %d exceeds the engine's max_batch %d" % (args.batch_size, model.max_batch))
     if getattr(args, "forward_precision", None) and model.precision != args.forward_precision:   # (`precision` is the P of P/R/F1 in the results)
-        model.set_precision(args.forward_precision)   # "split": the reference's fp32 forward to fp32 summation noise (wca_set_precision)
+        model.set_precision(args.forward_precision)   # "reference" / "split": the reference's fp32 forward to fp32 summation noise (wca_set_precision)
     if args.n_mels != model.dims.n_mels:
         raise SystemExit("--n_mels %d does not match the checkpoint (%d); large-v3 needs --n_mels 128" % (args.n_mels, model.dims.n_mels))
     tokenizer = get_tokenizer(model.is_multilingual, language="English", vocab_path=args.vocab)
@@ -364,9 +364,11 @@ def parse_args(argv=None):
     p.add_argument("--teacher", type=str, default=None, choices=["text", "asr"],
                    help="asr (default; needs --vocab): greedy decode pre-pass gives the teacher text, the reference's behaviour; "
                         "text: teacher-force the dataset transcript (not the reference's protocol)")
-    p.add_argument("--forward_precision", type=str, default="f16", choices=["f16", "split"],
-                   help="f16 (default): operands rounded to f16 once, fastest; split: reference precision -- every operand as an f16 hi / lo "
-                        "pair against the exact f16 weights (the reference's fp32 forward to fp32 summation noise, ~2x the time)")
+    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "f16", "split"],
+                   help="reference (default): the contract mode -- the encoder blocks, the cross-K/V projection and the decoder carry their "
+                        "operands as f16 hi / lo pairs against the exact f16 weights (the reference's fp32 forward to fp32 summation noise; word "
+                        "times equal the CPU reference's); split: the log-mel and the conv stem too (+1 %% time, no measured difference); "
+                        "f16: operands rounded to f16 once -- 1.9x faster, word times within one frame for ~98.5 %% of the boundaries")
     p.add_argument("--readers", type=int, default=4, help="reader threads (audio decode + tokenisation ahead of the GPU)")
     return p.parse_args(argv)
 

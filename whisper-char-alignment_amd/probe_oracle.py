@@ -149,7 +149,7 @@ def parse_args(argv=None):
     p.add_argument("--tolerance", type=float, default=0.02)
     p.add_argument("--plot", action="store_true")
     p.add_argument("--strict", action="store_true")
-    p.add_argument("--forward_precision", type=str, default="f16", choices=["f16", "split"], help="forward arithmetic (see infer_ali.py --forward_precision)")
+    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "f16", "split"], help="forward arithmetic (see infer_ali.py --forward_precision)")
     p.add_argument("--weights", type=str, default=None)
     p.add_argument("--random_init", action="store_true")
     p.add_argument("--vocab", type=str, default=None)
