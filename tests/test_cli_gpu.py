@@ -88,7 +88,7 @@ def test_infer_ali_precision_split(corpus):
     assert sorted(preds["split"]) == sorted(preds["f16"]) == [0, 1, 2, 3, 4]
     same = sum(int(np.array_equal(preds["f16"][n]["ends_hat"], preds["split"][n]["ends_hat"])) for n in preds["f16"])
     assert same >= 3, same
-    # the contract mode and the all-sites mode: the same word times (log-mel / conv stem on single operands changes nothing here)
+    # "reference" (the default) and "split" name the same mode
     assert all(np.array_equal(preds["reference"][n]["ends_hat"], preds["split"][n]["ends_hat"]) for n in preds["split"])
 
 

@@ -255,7 +255,7 @@ def test_contract_mode_parity_no_exclusions(wca):
     """THE GATE of the contract line (north_star: word start / end times within one 20 ms encoder frame of the reference CPU path on
     the same audio + text). The headline configuration -- whisper-medium dimensions, PEAKY seeded weights (cross_qk_std = 0.08), 10 s
     audio, 64-char text, topk 10, medfilt 3 -- through the FUSED wca_align_batch at B = 64 in the engine's REFERENCE precision mode
-    (wca_set_precision(WCA_PRECISION_REFERENCE), what bench.py's `value` runs), on ids 100-131 + the bench's own ids 10000-10031,
+    (wca_set_precision(WCA_PRECISION_REFERENCE) = every site split; what bench.py's `value` runs), on ids 100-131 + the bench's own ids 10000-10031,
     which include utterances whose oracle head scores are tied to 4e-6 / 3e-4 and every known miss of the f16 mode. EVERY boundary
     of EVERY utterance must be within one frame of the fp32 CPU oracle's: no acceptance set, no excused utterance.
     The oracle's word times come from tests/golden/oracle_word_times_medium_peaky.npz (tests/golden/make_oracle_word_times.py);
@@ -265,7 +265,7 @@ def test_contract_mode_parity_no_exclusions(wca):
     syn, tk, rt, tm, audio = _mods()
     dims, sd, model, tok, utts, args, gold = _gate_batch(wca)
     model.set_precision("reference")
-    assert model.precision == "reference" and model.precision_sites == (["enc_gemm", "enc_attn", "cross_kv", "dec", "capture"], 0)
+    assert model.precision == "split" and model.precision_sites[0] == ["logmel", "conv", "enc_gemm", "enc_attn", "cross_kv", "dec", "capture"]
     jump, sel = model.align_batch(*args)
     total, within, ident, offenders = _boundary_stats(tm, tok, utts, jump, gold)
     print("contract mode, medium B=64 fused: %d boundaries over %d utterances, within one frame %d, identical %d, offenders %s"

@@ -1565,15 +1565,13 @@ int wca_get_precision_sites(wca_engine* e, unsigned* mask_out, int* enc_first_la
 
 int wca_set_precision(wca_engine* e, int mode) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
-  if (mode != WCA_PRECISION_F16 && mode != WCA_PRECISION_SPLIT && mode != WCA_PRECISION_REFERENCE) return fail(WCA_ERR_INVALID, "precision mode %d", mode);
-  return wca_set_precision_sites(e, mode == WCA_PRECISION_SPLIT ? (unsigned)WCA_PSITE_ALL : mode == WCA_PRECISION_REFERENCE ? (unsigned)WCA_PSITE_REFERENCE : 0u, 0);
+  if (mode != WCA_PRECISION_F16 && mode != WCA_PRECISION_SPLIT) return fail(WCA_ERR_INVALID, "precision mode %d", mode);
+  return wca_set_precision_sites(e, mode == WCA_PRECISION_SPLIT ? (unsigned)WCA_PSITE_ALL : 0u, 0);
 }
 
 int wca_get_precision(wca_engine* e) {
   if (!e || e->sites == 0) return WCA_PRECISION_F16;
-  if (e->enc_from == 0 && e->sites == (unsigned)WCA_PSITE_ALL) return WCA_PRECISION_SPLIT;
-  if (e->enc_from == 0 && e->sites == (unsigned)WCA_PSITE_REFERENCE) return WCA_PRECISION_REFERENCE;
-  return WCA_PRECISION_MIXED;
+  return (e->sites == (unsigned)WCA_PSITE_ALL && e->enc_from == 0) ? WCA_PRECISION_SPLIT : WCA_PRECISION_MIXED;
 }
 
 int wca_set_fuse_ln(wca_engine* e, int on) {

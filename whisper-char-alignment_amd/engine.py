@@ -448,12 +448,11 @@ class WhisperAMD:
         return tuple(int(v) for v in arr)
 
     def set_precision(self, mode):
-        """'f16' (the engine's default): operands rounded to f16 once, fp32 accumulation. 'split': every operand of every stage as an
-        f16 (hi, lo) pair against the exact f16 weights, three-pass attention (wca.h: wca_set_precision). 'reference': the contract
-        mode -- the same from the encoder blocks on, log-mel and conv stem on single operands (the cheapest site set that reproduces
-        the fp32 reference's word times with no exception; what bench.py's `value` and the CLI default use). No batch may be in
-        flight; the activation arena is re-created when the engine leaves or enters f16."""
-        modes = {"f16": 0, "split": 1, "reference": 3}
+        """'f16' (the engine's construction default): operands rounded to f16 once, fp32 accumulation. 'split' = 'reference' (the
+        contract mode: what bench.py's `value` and the CLI default use): every operand of every stage as an f16 (hi, lo) pair against
+        the exact f16 weights, three-pass attention (wca.h: wca_set_precision) -- the reference's fp32 forward to fp32 summation noise.
+        No batch may be in flight; the activation arena is re-created when the engine leaves or enters f16."""
+        modes = {"f16": 0, "split": 1, "reference": 1}
         if mode not in modes:
             raise ValueError("precision must be 'f16', 'reference' or 'split'")
         _lib.check(self._lib.wca_set_precision(self._h, modes[mode]))
@@ -486,7 +485,7 @@ class WhisperAMD:
 
     @property
     def precision(self):
-        return {0: "f16", 1: "split", 2: "mixed", 3: "reference"}[self._lib.wca_get_precision(self._h)]
+        return {0: "f16", 1: "split", 2: "mixed"}[self._lib.wca_get_precision(self._h)]   # ("reference" is an alias of "split")
 
     def set_fuse_ln(self, on):
         """LayerNorm in the residual GEMMs' epilogue (needs the GPU to itself: wca.h) or as separate launches (the default)."""

@@ -150,7 +150,7 @@ def infer_dataset(args, model=None):
         model = load_model(args, device)
     if args.batch_size > model.max_batch:
         raise SystemExit("--batch_size %d exceeds the engine's max_batch %d" % (args.batch_size, model.max_batch))
-    if getattr(args, "forward_precision", None) and model.precision != args.forward_precision:   # (`precision` is the P of P/R/F1 in the results)
+    if getattr(args, "forward_precision", None) and model.precision != {"reference": "split"}.get(args.forward_precision, args.forward_precision):   # (`precision` is the P of P/R/F1 in the results)
         model.set_precision(args.forward_precision)   # "reference" / "split": the reference's fp32 forward to fp32 summation noise (wca_set_precision)
     if args.n_mels != model.dims.n_mels:
         raise SystemExit("--n_mels %d does not match the checkpoint (%d); large-v3 needs --n_mels 128" % (args.n_mels, model.dims.n_mels))
@@ -364,10 +364,9 @@ def parse_args(argv=None):
     p.add_argument("--teacher", type=str, default=None, choices=["text", "asr"],
                    help="asr (default; needs --vocab): greedy decode pre-pass gives the teacher text, the reference's behaviour; "
                         "text: teacher-force the dataset transcript (not the reference's protocol)")
-    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "f16", "split"],
-                   help="reference (default): the contract mode -- the encoder blocks, the cross-K/V projection and the decoder carry their "
-                        "operands as f16 hi / lo pairs against the exact f16 weights (the reference's fp32 forward to fp32 summation noise; word "
-                        "times equal the CPU reference's); split: the log-mel and the conv stem too (+1 %% time, no measured difference); "
+    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "split", "f16"],
+                   help="reference (default; 'split' is the same mode): the contract mode -- every stage carries its operands as f16 hi / lo pairs "
+                        "against the exact f16 weights (the reference's fp32 forward to fp32 summation noise; word times equal the CPU reference's); "
                         "f16: operands rounded to f16 once -- 1.9x faster, word times within one frame for ~98.5 %% of the boundaries")
     p.add_argument("--readers", type=int, default=4, help="reader threads (audio decode + tokenisation ahead of the GPU)")
     return p.parse_args(argv)

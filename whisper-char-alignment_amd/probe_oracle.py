@@ -78,7 +78,7 @@ def infer_dataset(args):
     print(args)
     device = "cuda:0"
     model = load_model(args, device)
-    if model.precision != args.forward_precision:
+    if model.precision != {"reference": "split"}.get(args.forward_precision, args.forward_precision):
         model.set_precision(args.forward_precision)
     tokenizer = get_tokenizer(model.is_multilingual, language="English", vocab_path=args.vocab)
     dataset = DATASET[args.dataset](args.scp, n_mels=args.n_mels, device=device, model=model, compute_mel=True)
@@ -149,7 +149,7 @@ def parse_args(argv=None):
     p.add_argument("--tolerance", type=float, default=0.02)
     p.add_argument("--plot", action="store_true")
     p.add_argument("--strict", action="store_true")
-    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "f16", "split"], help="forward arithmetic (see infer_ali.py --forward_precision)")
+    p.add_argument("--forward_precision", type=str, default="reference", choices=["reference", "split", "f16"], help="forward arithmetic (see infer_ali.py --forward_precision)")
     p.add_argument("--weights", type=str, default=None)
     p.add_argument("--random_init", action="store_true")
     p.add_argument("--vocab", type=str, default=None)
