@@ -14,6 +14,8 @@
 // with the slot that tile kt + 1 is then requested into). Scores transposed (S^T = K Q^T) so that a query row is a lane column;
 // textbook online softmax in fp32 on the RAW scores (no deferred maximum, no pre-scaled Q: nothing is rounded to f16 before
 // the exponential); P is split like every other operand.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -64,19 +66,32 @@ __device__ __forceinline__ half4 tr_read_asm(unsigned addr) {
     __builtin_amdgcn_sched_barrier(0);                                                                                               \
   } while (0)
 
-template <bool CAUSAL, bool CAPTURE>
-__global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
+// NW = waves per workgroup (32 query rows each): 4 everywhere (128-row blocks, two workgroups per CU = 2 waves per SIMD).
+// PMC counters of this kernel on the encoder's 64 x 16 x 1500 x 1500 shape (profiles/r04_attn_split_pmc.txt): matrix pipe busy 47 %,
+// vector ALU ~45 %, the two co-executing 7.5 % of the time, waves stalled at issue 49 %, parked at a wait 14.5 %, LDS index unit
+// 16 %, no bank conflicts -- 0.95 PFLOP/s executed, the same plateau as the pair GEMMs. Two restructurings were built, verified
+// against float64 and measured at that shape in round 4, neither pays:
+//   * the wave's two 16-row sub-blocks software-pipelined against each other (S(1) under the exp2 / pair split of block 0, P.V(0) under
+//     those of block 1: MFMAs under every vector stretch, K / V fragments of the whole tile held in registers, 212 VGPRs): 1.840 vs
+//     1.853 ms -- removed;
+//   * NW = 6 (192-row blocks, 384 threads, 166 VGPRs = three waves per SIMD, a third less K / V staging per query row): 2.116 vs
+//     1.844 ms (the 8 staging pieces do not divide over 6 waves and the barrier waits for the two that stage twice) -- kept only as
+//     AttnArgs.variant 2 for the A/B.
+// What did pay: the deferred running maximum below (1.869 -> 1.837 ms).
+template <bool CAUSAL, bool CAPTURE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);  // [slot][K hi | K lo | V hi | V lo]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fg = lane >> 4;
-  const int n_qt = (a.nq + 127) / 128;
+  constexpr int QB = NW * 32;  // query rows per workgroup
+  const int n_qt = (a.nq + QB - 1) / QB;
   const int lid = xcd_remap(blockIdx.x, n_qt * a.H * a.B);
   const int bh = lid / n_qt;
   const int b = bh / a.H, h = bh - b * a.H;
-  const int q_blk = (lid - bh * n_qt) * 128;
+  const int q_blk = (lid - bh * n_qt) * QB;
   const int q_wave = q_blk + wave * 32;
 
   // Q fragments (B operand of S^T = K Q^T): lane holds Q[q = fr][dd = ks*32 + 8*fg + j], hi and lo halves
@@ -96,7 +111,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
 
   int nk_eff = a.nk;
   if (CAUSAL) {
-    const int qhi = q_blk + 128;
+    const int qhi = q_blk + QB;
     nk_eff = qhi < a.nk ? qhi : a.nk;
   }
   const int nkt = (nk_eff + KT - 1) / KT;
@@ -111,9 +126,12 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
     half_t* Kl = Kh + TILE;
     half_t* Vh = Kl + TILE;
     half_t* Vl = Vh + TILE;
+    // the tile's 8 pieces of 8 key rows are dealt to the waves round-robin (NW = 6: waves 0, 1 stage two pieces, the others one)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rbase = (wave * 2 + i) * 8;
+    for (int i = 0; i < (8 + NW - 1) / NW; ++i) {
+      const int piece = wave + NW * i;
+      if (piece >= 8) break;   // (wave-uniform)
+      const int rbase = piece * 8;
       const int r = rbase + (lane >> 3);
       int key = kt * KT + r;
       key = key < a.nk ? key : a.nk - 1;  // rows past nk: a duplicate of the last key, masked to -inf below
@@ -346,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void attn_split_kernel(AttnArgs a) {
   }
 }
 
+
 }  // namespace
 
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
@@ -355,19 +374,24 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
   if ((a.q_lo % 8) || (a.k_lo % 8) || (a.v_lo % 8) || (a.o_lo % 4) || a.q_lo <= 0 || a.k_lo <= 0 || a.v_lo <= 0 || a.o_lo <= 0) return hipErrorInvalidValue;
   if (a.cap != nullptr && ((a.cap_ld % 4) != 0 || a.cap_ld < ((a.cap_cols + 3) & ~3))) return hipErrorInvalidValue;
   const bool cap = a.cap != nullptr && a.cap_cols > 0;
-  dim3 grid(((a.nq + 127) / 128) * a.H * a.B), block(256);
   const size_t shmem = 2 * 4 * TILE * sizeof(half_t);  // 64 KiB: two slots of K hi | K lo | V hi | V lo
-#define WCA_LAUNCH_AS(C, P)                                                                                                  \
+#define WCA_LAUNCH_AS(C, P, W)                                                                                               \
   do {                                                                                                                       \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<C, P>),                               \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split_kernel<C, P, W>),                            \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                             \
     if (e != hipSuccess) return e;                                                                                           \
-    hipLaunchKernelGGL((attn_split_kernel<C, P>), grid, block, shmem, s, a);                                                 \
+    hipLaunchKernelGGL((attn_split_kernel<C, P, W>), dim3(((a.nq + (W) * 32 - 1) / ((W) * 32)) * a.H * a.B), dim3((W) * 64), shmem, s, a); \
   } while (0)
+  static const int env_variant = getenv("WCA_ATTN_SPLIT_VARIANT") ? atoi(getenv("WCA_ATTN_SPLIT_VARIANT")) : 0;  // 2: six waves on long rows (A/B)
+  const int variant = a.variant ? a.variant : env_variant;
   if (a.causal) {
-    if (cap) WCA_LAUNCH_AS(true, true); else WCA_LAUNCH_AS(true, false);
+    if (cap) WCA_LAUNCH_AS(true, true, 4); else WCA_LAUNCH_AS(true, false, 4);
+  } else if (cap) {
+    WCA_LAUNCH_AS(false, true, 4);
+  } else if (a.nq >= 768 && variant == 2) {  // experiment: 192-row workgroups, three waves per SIMD (slower: see the kernel's header)
+    WCA_LAUNCH_AS(false, false, 6);
   } else {
-    if (cap) WCA_LAUNCH_AS(false, true); else WCA_LAUNCH_AS(false, false);
+    WCA_LAUNCH_AS(false, false, 4);
   }
 #undef WCA_LAUNCH_AS
   return hipGetLastError();
