@@ -411,6 +411,12 @@ int wca_get_precision_sites(wca_engine* e, unsigned* mask_out, int* enc_first_la
  * batch's phase 1; off: everything on one stream, so that rocprofv3 per-kernel durations are not inflated by sharing
  * the CUs (profiling aid; throughput drops by the overlap's worth). No batch may be in flight when it is changed. */
 int wca_set_overlap(wca_engine* e, int on);
+/* EXPERIMENT (measured in profiles/r04_cu_partition.txt, off by default): phase2_cus > 0 (a multiple of 8) gives phase 2
+ * of the alignment and the greedy decode loop CU-masked streams that own that many compute units (hipExtStreamCreateWithCUMask) and phase 1
+ * (log-mel, encoder, cross-K/V) the rest, its persistent GEMM grids sized to match -- so that the HBM-bound decode kernels run BESIDE
+ * the MFMA-bound encoder instead of queueing behind its persistent workgroups. 0 lifts the partition. While it is active
+ * wca_engine_set_stream is ignored (the caller's stream has no mask): inputs must be complete before an entry point is called. */
+int wca_set_cu_partition(wca_engine* e, int phase2_cus);
 /* Decoder GEMMs on few rows (a greedy-decode step of wca_greedy_decode: M = batch; batch-1 teacher-forced forwards):
  * fused != 0 (default): for up to 128 rows one few-row kernel per GEMM with the LayerNorm in its prologue, the KV-cache append in its
  * epilogue and deterministic split-K for K = 4 n_state; 0: separate LayerNorm / GEMM / append launches (the round-1 path,

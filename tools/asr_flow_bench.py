@@ -7,7 +7,9 @@ pcm = NULL) both re-use them; the next batch's phase 1 is enqueued before the cu
 With seeded random weights the decoder never emits <|endoftext|> by itself, so the number of sampled tokens is FIXED per run
 (EOT suppressed): a 64-character English sentence is 16-24 Whisper BPE tokens (+ 2 timestamp tokens); the teacher text that is
 aligned afterwards is the synthetic 64-character text of bench.py (the decoded ids are noise). Reports utterances/s and the
-split decode / align per batch.  usage: asr_flow_bench.py [B] [steps] [tokens,tokens,...]"""
+split decode / align per batch.  usage: asr_flow_bench.py [B] [steps] [tokens,tokens,...]
+Environment: WCA_PRECISION=f16|reference (default f16: round 3's record was taken in it); WCA_PART_CUS=32,64,... repeats the whole
+measurement with the engine's CU partition (wca_set_cu_partition: phase 2 + decode loop on that many CUs, phase 1 on the rest)."""
 import importlib
 import os
 import sys
@@ -29,6 +31,8 @@ token_counts = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "16,24,32
 dims = wca.dims_for(os.environ.get("WCA_MODEL", "medium"))
 m = wca.WhisperAMD(dims, max_batch=B)
 m.load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
+m.set_precision(os.environ.get("WCA_PRECISION", "f16"))
+print("forward precision:", m.precision, flush=True)
 tok = tok_mod.get_tokenizer(True, language="en")
 initial = list(tok.sot_sequence)
 sup = np.zeros(dims.n_vocab, np.uint8)
@@ -82,31 +86,39 @@ def text_teacher(n):
     fetch(n - 1)
 
 
-text_teacher(3)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-text_teacher(steps)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print("teacher = given text (bench.py's loop): %.1f ms per batch of %d -> %.0f utt/s" % (dt * 1e3 / steps, B, B * steps / dt), flush=True)
+def measure():
+    text_teacher(3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    text_teacher(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("teacher = given text (bench.py's loop): %.1f ms per batch of %d -> %.0f utt/s" % (dt * 1e3 / steps, B, B * steps / dt), flush=True)
 
-for sample_len in token_counts:
-    for rnd in range(2):   # round 0 = warm-up (buffer growth)
-        n = 3 if rnd == 0 else steps
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        t_dec = 0.0
-        encode(0)
-        for i in range(n):
-            if i + 1 < n:
-                encode(i + 1)          # phase 1 of the next batch runs beside this batch's decode loop
-            td = time.perf_counter()
-            decode(sample_len)         # returns when the loop has finished (host reads the tokens)
-            t_dec += time.perf_counter() - td
-            align(i)
-            fetch(i)                   # frees the K/V slot for batch i + 2
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-    print("teacher = ASR pre-pass, %2d sampled tokens (+%d prompt positions): %.1f ms per batch of %d (decode loop %.1f ms = %.2f ms per position, "
-          "rest %.1f ms) -> %.0f utt/s" % (sample_len, len(initial), dt * 1e3 / steps, B, t_dec * 1e3 / steps,
-                                           t_dec * 1e3 / steps / (sample_len + len(initial) - 1), (dt - t_dec) * 1e3 / steps, B * steps / dt), flush=True)
+    for sample_len in token_counts:
+        for rnd in range(2):   # round 0 = warm-up (buffer growth)
+            n = 3 if rnd == 0 else steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            t_dec = 0.0
+            encode(0)
+            for i in range(n):
+                if i + 1 < n:
+                    encode(i + 1)          # phase 1 of the next batch runs beside this batch's decode loop
+                td = time.perf_counter()
+                decode(sample_len)         # returns when the loop has finished (host reads the tokens)
+                t_dec += time.perf_counter() - td
+                align(i)
+                fetch(i)                   # frees the K/V slot for batch i + 2
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        print("teacher = ASR pre-pass, %2d sampled tokens (+%d prompt positions): %.1f ms per batch of %d (decode loop %.1f ms = %.2f ms per position, "
+              "rest %.1f ms) -> %.0f utt/s" % (sample_len, len(initial), dt * 1e3 / steps, B, t_dec * 1e3 / steps,
+                                               t_dec * 1e3 / steps / (sample_len + len(initial) - 1), (dt - t_dec) * 1e3 / steps, B * steps / dt), flush=True)
+
+
+for part in [0] + [int(x) for x in os.environ.get("WCA_PART_CUS", "").split(",") if x]:
+    m.set_cu_partition(part)
+    print("---- CU partition: %s" % ("off (every stream may use all %d CUs)" % 256 if part == 0 else "phase 2 / decode loop on %d CUs, phase 1 on the rest" % part), flush=True)
+    measure()
+m.set_cu_partition(0)

@@ -36,13 +36,25 @@ SITES = {  # site -> (kernel-name substring, lambda(M, d) -> (N, K), read-modify
 }
 
 
+# the pair-operand kernels of the reference precision mode (WCA_PRECISION=reference): A rows and f16 outputs are (hi, lo) pairs
+SITES_REFERENCE = {
+    "qkv": ("gemm256p_f16_kernel<4, false, 1, false, true>", lambda d: (3 * d, d), False),
+    "out_proj": ("gemm256p_f16_kernel<2, false, 1, false, true>", lambda d: (d, d), True),
+    "fc1": ("gemm256p_f16_kernel<4, true, 1, false, true>", lambda d: (4 * d, d), False),
+    "fc2": ("gemm256p_f16_kernel<2, false, 4, false, true>", lambda d: (d, 4 * d), True),
+    "attention": ("attn_split_kernel<false, false, 4>", None, False),
+}
+
+
 def main():
-    """usage: pmc_traffic.py <FETCH_SIZE pass dir> <WRITE_SIZE pass dir> <out.json> <site> [batch] [model] [d]"""
+    """usage: [WCA_PRECISION=reference] pmc_traffic.py <FETCH_SIZE pass dir> <WRITE_SIZE pass dir> <out.json> <site> [batch] [model] [d]"""
     fetch_dir, write_dir, out, site = sys.argv[1:5]
     batch = int(sys.argv[5]) if len(sys.argv) > 5 else 64
     model = sys.argv[6] if len(sys.argv) > 6 else "medium"
     d = int(sys.argv[7]) if len(sys.argv) > 7 else 1024
-    needle, nk, rmw = SITES[site]
+    precision = os.environ.get("WCA_PRECISION", "f16")
+    pair = precision != "f16"
+    needle, nk, rmw = (SITES_REFERENCE if pair else SITES)[site]
     fetch_kb, n = per_launch(fetch_dir, "FETCH_SIZE", needle)
     write_kb, _ = per_launch(write_dir, "WRITE_SIZE", needle)
     # rocprofv3's derived FETCH_SIZE / WRITE_SIZE are in units of 1024 bytes
@@ -50,15 +62,18 @@ def main():
     M = batch * 1500
     if nk is not None:
         N, K = nk(d)
-        algo = (M * K + N * K) * 2 + N * 4 + (M * N * 10 if rmw else M * N * 2)   # rmw: f32 residual read + write, + the fused LayerNorm's f16 output
+        if pair:   # A rows [hi | lo], the PLAIN W read once, f16 outputs as pairs; rmw: f32 residual read + write (the LayerNorm is its own launch)
+            algo = M * K * 4 + N * K * 2 + N * 4 + (M * N * 8 if rmw else M * N * 4)
+        else:
+            algo = (M * K + N * K) * 2 + N * 4 + (M * N * 10 if rmw else M * N * 2)   # rmw: f32 residual read + write, + the fused LayerNorm's f16 output
     else:
         N = K = None
-        algo = (M * 3 * d + M * d) * 2
+        algo = (M * 3 * d + M * d) * (4 if pair else 2)
     import subprocess
     # the GPU box has no .git: the collecting command passes the hash in (WCA_COMMIT=$(git rev-parse --short HEAD) expanded where the repo is)
     head = os.environ.get("WCA_COMMIT") or subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     res = {
-        "site": site, "kernel": needle, "batch": batch, "model": model, "M": M, "N": N, "K": K, "launches_averaged": n, "commit": head,
+        "site": site, "precision": "reference" if pair else "f16", "kernel": needle, "batch": batch, "model": model, "M": M, "N": N, "K": K, "launches_averaged": n, "commit": head,
         "FETCH_SIZE_raw_bytes": fetch_b, "FETCH_SIZE_corrected_x2_bytes": 2.0 * fetch_b, "WRITE_SIZE_bytes": write_b,
         "traffic_bytes_per_launch": 2.0 * fetch_b + write_b,
         "algorithmic_bytes_per_launch": algo,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "wca_set_profiling": (_i, [_vp, _i]),
     "wca_last_kernel_ms": (_i, [_vp, _i, C.POINTER(C.c_int), _pf, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "wca_set_overlap": (_i, [_vp, _i]),
+    "wca_set_cu_partition": (_i, [_vp, _i]),
     "wca_set_fuse_ln": (_i, [_vp, _i]),
     "wca_set_precision": (_i, [_vp, _i]),
     "wca_get_precision": (_i, [_vp]),

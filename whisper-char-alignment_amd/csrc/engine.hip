@@ -226,6 +226,9 @@ struct wca_engine {
                              // the GPU to itself -- with a second process (or engine) on the device two such launches can hold each
                              // other's CUs and run into the bounded spin's time-out (measured: two bench ranks on one GPU)
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
+  int part_cus = 0;          // wca_set_cu_partition: > 0 = phase 2 / the decode loop own that many CUs (CU-masked streams), phase 1 the rest
+  hipStream_t part_s1 = nullptr, part_s2 = nullptr, part_s3 = nullptr;  // the masked streams: they REPLACE stream / stream2 / stream3 while active
+  hipStream_t saved_s2 = nullptr, saved_s3 = nullptr;                   // ... and the engine's own ones come back when the partition is lifted
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
                              // back to back, not concurrently -- 3.86 vs 3.90 ms per step -- so one stream is the default)
@@ -463,10 +466,13 @@ int ensure_split_weights(wca_engine* e) {
 }
 
 // c_lo > 0 (split mode, f16 output): the value is stored as the pair hi at C, lo at C + c_lo (out_mode 4)
+thread_local int g_gemm_cu_limit = 0;  // CUs owned by the stream the current phase launches on (0 = the whole device)
+
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
                 int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0, long a_lo = 0) {
   GemmArgs g{};
   g.a_lo = a_lo;
+  g.cu_limit = g_gemm_cu_limit;
   g.sk_part = sk_ws;
   g.sk_bytes = sk_bytes;
   g.c_lo = c_lo;
@@ -1186,11 +1192,14 @@ int run_phase1(wca_engine* e, const float* mel_dev, const float* pcm_dev, int64_
   record(e, 1);
   e->ln_err = e->err_dev + 1 + slot;
   HIPCHK(hipMemsetAsync(e->ln_err, 0, sizeof(int), e->stream));
+  g_gemm_cu_limit = e->part_cus > 0 ? e->n_cu - e->part_cus : 0;   // persistent GEMM grids = the CUs phase 1's stream owns
   int rc = run_encoder(e, batch);
   e->ln_err = e->err_dev;
-  if (rc) return rc;
-  record(e, 2);
-  rc = run_cross_kv(e, batch, kvbuf, skip_last_v);
+  if (!rc) {
+    record(e, 2);
+    rc = run_cross_kv(e, batch, kvbuf, skip_last_v);
+  }
+  g_gemm_cu_limit = 0;
   if (rc) return rc;
   record(e, 3);
   HIPCHK(hipEventRecord(e->ev_kv[slot], e->stream));
@@ -1379,6 +1388,11 @@ void wca_engine_destroy(wca_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
   (void)hipDeviceSynchronize();
+  if (e->part_s1) {
+    e->enq_count = e->fetch_count;
+    e->enc_q.clear();
+    (void)wca_set_cu_partition(e, 0);
+  }
   for (GrowBuf* g : {&e->cap, &e->wws, &e->colnorm, &e->scores, &e->sel, &e->selsc, &e->matrix, &e->trace, &e->path, &e->pathlen,
                      &e->jump, &e->tmp0, &e->tmp1})
     g->release();
@@ -1420,6 +1434,7 @@ void wca_engine_destroy(wca_engine* e) {
 
 int wca_engine_set_stream(wca_engine* e, void* hip_stream) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (e->part_cus > 0) return WCA_OK;   // CU-partitioned engine (wca_set_cu_partition): phase 1 stays on its masked stream
   e->stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream, which is what torch's default stream is
   return WCA_OK;
 }
@@ -1577,6 +1592,39 @@ int wca_get_precision(wca_engine* e) {
 int wca_set_fuse_ln(wca_engine* e, int on) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   e->fuse_ln = on != 0;
+  return WCA_OK;
+}
+
+int wca_set_cu_partition(wca_engine* e, int phase2_cus) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (phase2_cus < 0 || phase2_cus >= e->n_cu || (phase2_cus & 7)) return fail(WCA_ERR_INVALID, "phase2_cus %d: a multiple of 8 in [0, %d)", phase2_cus, e->n_cu);
+  if (e->enq_count != e->fetch_count || !e->enc_q.empty()) return fail(WCA_ERR_STATE, "fetch / consume the batches in flight before changing the CU partition");
+  HIPCHK(hipSetDevice(e->device));
+  HIPCHK(hipDeviceSynchronize());
+  if (e->part_s1) {
+    e->stream = e->own_stream;
+    e->stream2 = e->saved_s2;
+    e->stream3 = e->saved_s3;
+    (void)hipStreamDestroy(e->part_s1);
+    (void)hipStreamDestroy(e->part_s2);
+    (void)hipStreamDestroy(e->part_s3);
+    e->part_s1 = e->part_s2 = e->part_s3 = nullptr;
+  }
+  e->part_cus = 0;
+  if (phase2_cus == 0) return WCA_OK;
+  // mask bit i = CU i of the device's enumeration; the round-robin of mask bits over the 8 XCDs gives both partitions CUs on every XCD
+  const int words = (e->n_cu + 31) / 32;
+  std::vector<uint32_t> m1(words, 0u), m2(words, 0u);
+  for (int i = 0; i < e->n_cu; ++i) (i < phase2_cus ? m2 : m1)[i >> 5] |= 1u << (i & 31);
+  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s1, (uint32_t)words, m1.data()));
+  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s2, (uint32_t)words, m2.data()));
+  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s3, (uint32_t)words, m2.data()));
+  e->saved_s2 = e->stream2;
+  e->saved_s3 = e->stream3;
+  e->stream = e->part_s1;   // (wca_engine_set_stream is ignored while the partition is active: the caller's stream has no CU mask)
+  e->stream2 = e->part_s2;
+  e->stream3 = e->part_s3;
+  e->part_cus = phase2_cus;
   return WCA_OK;
 }
 

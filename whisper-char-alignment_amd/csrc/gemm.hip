@@ -896,6 +896,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (e != hipSuccess) return e;
     n_cu_cache[dev & 31].store(n_cu, std::memory_order_relaxed);
   }
+  if (a.cu_limit > 0 && a.cu_limit < n_cu) n_cu = a.cu_limit;   // a CU-masked stream: one persistent workgroup per CU it owns
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;

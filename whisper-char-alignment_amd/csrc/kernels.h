@@ -51,6 +51,7 @@ struct GemmArgs {
   int site;                // 0 generic, 1 encoder block (QKV / out-projection / fc1), 2 decoder, 3 conv stem / cross-KV / logits,
                            // 4 encoder fc2: selects a distinct kernel symbol per call site so rocprofv3 --stats separates them
   int supertile;           // 256x256 persistent kernel: m-panels per supertile of the tile order (0 = chosen by launch_gemm)
+  int cu_limit;            // > 0: the stream this launch goes to owns only that many CUs (wca_set_cu_partition): size of the persistent grid
   // ---- few-row kernel only (gemm_rows.hip, launch_gemm_rows):
   const float* A32;        // non-null: the A operand is LayerNorm(A32 rows; ln_gamma, ln_beta, ln_eps) computed in the prologue
   int lda32;               // floats between A32 rows (K == row length)

@@ -495,6 +495,12 @@ class WhisperAMD:
         """Phase 2 on its own stream (default) or everything on one stream (clean per-kernel profiles)."""
         _lib.check(self._lib.wca_set_overlap(self._h, 1 if on else 0))
 
+    def set_cu_partition(self, phase2_cus):
+        """Experiment (wca.h: wca_set_cu_partition): phase 2 / the decode loop on CU-masked streams owning `phase2_cus` compute units,
+        phase 1 on the rest; 0 lifts it. Inputs must be complete (synchronised) before the engine is called while it is active."""
+        torch.cuda.synchronize()
+        _lib.check(self._lib.wca_set_cu_partition(self._h, int(phase2_cus)))
+
     def set_decode_mode(self, fused=True, streams=1):
         """Few-row decoder GEMMs fused with LayerNorm / KV append / split-K (default) or separate launches; greedy decode as
         one stream (default) or two interleaved half-batches."""
