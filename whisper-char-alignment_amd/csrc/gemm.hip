@@ -967,7 +967,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 4); else if ((S) == 3) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 3); else WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 1); } \
+    if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 4); else if ((S) == 3) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 3); else if ((S) == 2) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 2); else WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 1); } \
     else if (pipelined && a.dbg) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, S, true); \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
