@@ -181,7 +181,7 @@ def test_split_attention_is_fp32_accurate(eng, lib, wca, B, H, nq, nk, causal, c
 
 def test_split_layernorm_pairs(eng, lib, wca):
     g = torch.Generator().manual_seed(3)
-    for d in (384, 1024, 1280):
+    for d in (384, 512, 768, 1024, 1280):   # 384: the four-wide pair kernel; the others: eight elements per lane (odd chunk counts at 768 / 1280)
         x = torch.randn(37, d, generator=g) * 3 + 1
         gm, bt = torch.randn(d, generator=g), torch.randn(d, generator=g)
         out2 = torch.empty(37, 2 * d, dtype=torch.float16, device="cuda")

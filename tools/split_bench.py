@@ -60,6 +60,16 @@ def main():
         fl = 2.0 * M * n * k
         print("gemm %-4s M=%d N=%d K=%d  " % (name, M, n, k) + "  ".join("%s %.3f ms (%.0f TF alg)" % (kk, min(v), fl / min(v) / 1e9) for kk, v in t.items()), flush=True)
         del a, hi, a2, w, w2, out
+    if not only or only == "ln":
+        # pair LayerNorm (f32 rows -> [hi | lo] f16 rows): HBM-bound, 8 bytes per element
+        x = torch.randn(M, 1024, device="cuda")
+        g_, b_ = torch.ones(1024, device="cuda"), torch.zeros(1024, device="cuda")
+        y2 = torch.empty(M, 2048, device="cuda", dtype=torch.float16)
+        y1 = torch.empty(M, 1024, device="cuda", dtype=torch.float16)
+        t2 = min(timeit(lambda: chk(lib.wca_test_layernorm_split(eng._h, vp(x), vp(g_), vp(b_), vp(y2), M, 1024))) for _ in range(reps))
+        t1 = min(timeit(lambda: chk(lib.wca_test_layernorm(eng._h, vp(x), vp(g_), vp(b_), vp(y1), M, 1024))) for _ in range(reps))
+        print("layernorm rows=%d d=1024  single %.3f ms (%.2f TB/s)  pair %.3f ms (%.2f TB/s)" % (M, t1, M * 1024 * 6 / t1 / 1e9, t2, M * 1024 * 8 / t2 / 1e9), flush=True)
+        del x, y1, y2
     if only and only not in ("attn",):
         return
     H, S = 16, 1500

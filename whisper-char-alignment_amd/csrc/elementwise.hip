@@ -1,6 +1,8 @@
 // Row-wise small ops of the Whisper forward (HBM-bound, one wave per row, vectorised I/O).
 //   layernorm_f16 : whisper.model.LayerNorm (fp32 statistics, eps 1e-5) feeding an f16 GEMM operand
 //   embed         : token_embedding[tokens] + positional_embedding[:n]   (TextDecoder.forward)
+#include <cstdlib>
+
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -59,6 +61,74 @@ __global__ __launch_bounds__(256) void layernorm_f16_v4_kernel(const float* __re
     }
     o4[i * 64 + lane] = o;
     if (SPLIT) l4[i * 64 + lane] = ol;
+  }
+}
+
+// Pair output (SPLIT sites) with 16-byte stores: a lane owns EIGHT consecutive elements per 512-element chunk (two adjacent 16-byte
+// loads, one half8 store each for the hi and the lo row half) instead of four -- the pair LayerNorm writes as many bytes as it reads,
+// and the 8-byte stores of the kernel above held it at 4.4 TB/s (0.177 ms per 96000 x 1024 launch, 49 launches = 4.3 % of the
+// contract-mode step). An odd NV leaves one 256-element chunk in the four-wide mapping. Same arithmetic; the fp32 summation order of
+// the row statistics differs from the single-output kernel's (whose order gemm_rows.hip's LayerNorm prologue reproduces bit for bit).
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_pair_v8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, half_t* __restrict__ out, int rows, float eps,
+                                                                int ld_out, long lo_off) {
+  constexpr int d = 256 * NV, NC = NV / 2;  // NC chunks of 512 elements (+ one of 256 when NV is odd)
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * d;
+  f32x4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    v[2 * c] = *reinterpret_cast<const f32x4*>(xr + c * 512 + lane * 8);
+    v[2 * c + 1] = *reinterpret_cast<const f32x4*>(xr + c * 512 + lane * 8 + 4);
+  }
+  if (NV & 1) v[NV - 1] = *reinterpret_cast<const f32x4*>(xr + NC * 512 + lane * 4);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) * (1.0f / d);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float t = v[i][j] - mean;
+      q += t * t;
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / d) + eps);
+  half_t* orow = out + (long)row * ld_out;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int e0 = c * 512 + lane * 8;
+    half8 o, ol;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e0 + 4 * h), bb = *reinterpret_cast<const f32x4*>(beta + e0 + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const HalfPair pr = split_pair((v[2 * c + h][j] - mean) * rstd * g[j] + bb[j]);
+        o[4 * h + j] = pr.hi;
+        ol[4 * h + j] = pr.lo;
+      }
+    }
+    *reinterpret_cast<half8*>(orow + e0) = o;
+    *reinterpret_cast<half8*>(orow + lo_off + e0) = ol;
+  }
+  if (NV & 1) {
+    const int e0 = NC * 512 + lane * 4;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + e0), bb = *reinterpret_cast<const f32x4*>(beta + e0);
+    half4 o, ol;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const HalfPair pr = split_pair((v[NV - 1][j] - mean) * rstd * g[j] + bb[j]);
+      o[j] = pr.hi;
+      ol[j] = pr.lo;
+    }
+    *reinterpret_cast<half4*>(orow + e0) = o;
+    *reinterpret_cast<half4*>(orow + lo_off + e0) = ol;
   }
 }
 
@@ -155,6 +225,17 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
     if (lo_off) hipLaunchKernelGGL((KERN<NV, true>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off);           \
     else hipLaunchKernelGGL((KERN<NV, false>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off);                 \
   } while (0)
+  // pair output on rows of >= 512 elements with 16-byte aligned halves: the eight-elements-per-lane kernel (16-byte stores)
+  static const bool pair_v8 = getenv("WCA_LN_PAIR_V4") == nullptr;   // (WCA_LN_PAIR_V4=1: the four-wide kernel, for the A/B)
+  if (lo_off && pair_v8 && d >= 512 && (d % 256) == 0 && (ld_out & 7) == 0 && (lo_off & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    switch (d) {
+      case 512: hipLaunchKernelGGL((layernorm_pair_v8_kernel<2>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off); return hipGetLastError();
+      case 768: hipLaunchKernelGGL((layernorm_pair_v8_kernel<3>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off); return hipGetLastError();
+      case 1024: hipLaunchKernelGGL((layernorm_pair_v8_kernel<4>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off); return hipGetLastError();
+      case 1280: hipLaunchKernelGGL((layernorm_pair_v8_kernel<5>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off); return hipGetLastError();
+      default: break;
+    }
+  }
   switch (d) {
     case 128: WCA_LN(layernorm_f16_v2_kernel, 1); break;
     case 256: WCA_LN(layernorm_f16_v4_kernel, 1); break;

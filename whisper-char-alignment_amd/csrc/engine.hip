@@ -1487,17 +1487,21 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
   }
   *n_launches = nl;
   *total_ms = tot;
-  // algorithmic work of ONE launch at the last batch size (M = batch * 1500 rows, d = n_audio_state)
+  // algorithmic work of ONE launch at the last batch size (M = batch * 1500 rows, d = n_audio_state). Bytes: operands read once, outputs
+  // written once; an operand / output of a split site is an f16 PAIR (4 bytes per element instead of 2), the weights are read once
   const double d = e->dims.n_audio_state, M = (double)e->last_batch * N_CTX, H = e->dims.n_audio_head;
+  const int lastl = e->dims.n_audio_layer - 1;
+  const double pg = enc_gemm_split(e, lastl) ? 2.0 : 1.0, pa = enc_attn_split(e, lastl) ? 2.0 : 1.0;   // (the last block's flags: all blocks alike in the named modes)
+  const double pin_out = (pg > 1.0 && pa > 1.0) ? 2.0 : 1.0;   // the out-projection multiplies pairs only behind a split attention
   double fl = 0, by = 0;
   switch (site) {
-    case WCA_SITE_QKV: fl = 2 * M * 3 * d * d; by = 2 * (M * d + 3 * d * d + M * 3 * d); break;
-    case WCA_SITE_ATTN: fl = 4.0 * e->last_batch * H * (double)N_CTX * N_CTX * 64; by = 2 * (M * 3 * d + M * d); break;
-    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (M * d + d * d) + 8 * M * d + (e->fuse_ln ? 2 : 0) * M * d; break;  // f32 residual read + write (+ the fused LayerNorm's f16 output)
-    case WCA_SITE_FC1: fl = 2 * M * 4 * d * d; by = 2 * (M * d + 4 * d * d + M * 4 * d); break;
-    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (M * 4 * d + 4 * d * d) + 8 * M * d + (e->fuse_ln ? 2 : 0) * M * d; break;
+    case WCA_SITE_QKV: fl = 2 * M * 3 * d * d; by = 2 * (pg * M * d + 3 * d * d + pa * M * 3 * d); break;
+    case WCA_SITE_ATTN: fl = 4.0 * e->last_batch * H * (double)N_CTX * N_CTX * 64; by = 2 * pa * (M * 3 * d + M * d); break;
+    case WCA_SITE_OUT: fl = 2 * M * d * d; by = 2 * (pin_out * M * d + d * d) + 8 * M * d + (e->fuse_ln && pg == 1.0 ? 2 : 0) * M * d; break;  // f32 residual read + write (+ the fused LayerNorm's f16 output)
+    case WCA_SITE_FC1: fl = 2 * M * 4 * d * d; by = 2 * (pg * M * d + 4 * d * d + pg * M * 4 * d); break;
+    case WCA_SITE_FC2: fl = 2 * M * 4 * d * d; by = 2 * (pg * M * 4 * d + 4 * d * d) + 8 * M * d + (e->fuse_ln && pg == 1.0 ? 2 : 0) * M * d; break;
     case WCA_SITE_LN1:
-    case WCA_SITE_LN2: fl = 8 * M * d; by = 6 * M * d; break;                                    // read f32, write f16
+    case WCA_SITE_LN2: fl = 8 * M * d; by = (4 + 2 * pg) * M * d; break;                         // read f32, write f16 (or the f16 pair)
   }
   *flops_per_launch = fl;
   *bytes_per_launch = by;
