@@ -149,7 +149,8 @@ def _attn_ref64(q, k, v, H, causal):
 @pytest.mark.parametrize("B,H,nq,nk,causal,cap_cols", [
     (2, 3, 150, 200, 0, 0), (1, 2, 70, 70, 1, 0), (2, 6, 69, 1500, 0, 500), (1, 4, 448, 1500, 0, 1500), (1, 2, 300, 300, 1, 0),
     (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0), (1, 2, 97, 33, 0, 0), (3, 1, 129, 64, 1, 0), (1, 5, 2, 65, 0, 64),
-    (1, 2, 128, 64, 0, 0), (2, 2, 257, 129, 0, 0), (1, 3, 300, 1, 0, 0)])
+    (1, 2, 128, 64, 0, 0), (2, 2, 257, 129, 0, 0), (1, 3, 300, 1, 0, 0), (1, 2, 600, 130, 0, 0), (1, 1, 512, 64, 0, 0), (2, 1, 700, 128, 0, 0),
+    (1, 2, 1030, 260, 0, 0)])
 def test_split_attention_is_fp32_accurate(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
     """attn_split_kernel (three MFMA passes per product on hi / lo pairs, fp32 online softmax on the exact logits) against a
     float64 attention: output and captured logits at fp32 accuracy. A few large logits exercise the running-maximum update."""

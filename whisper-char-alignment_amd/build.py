@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # attention.hip: no NaN can occur in the online softmax (masked scores are -inf, the -inf - -inf cases are guarded), and
 # without this flag every fmaxf on a cross-lane / MFMA result is preceded by a canonicalising v_max_f32 x, x
 # (16 of the 24 v_max per 64-key tile, in a VALU-bound loop)
-EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"attention.hip": ["-fno-honor-nans"], "attention_split.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():

@@ -60,6 +60,17 @@ __device__ __forceinline__ half4 tr_read_asm(unsigned addr) {
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
   return r;
 }
+template <int OFF>
+__device__ __forceinline__ half8 b128_read_asm(unsigned addr) {
+  half8 r;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+  return r;
+}
+#define WCA_S_LGKM_WAIT4(N, A, B, C, D)                                                                       \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A), "+v"(B), "+v"(C), "+v"(D)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  } while (0)
 #define WCA_S_LGKM_WAIT8(N, A, B, C, D, E, F, G, H)                                                                                  \
   do {                                                                                                                               \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H)::"memory");  \
@@ -75,9 +86,14 @@ __device__ __forceinline__ half4 tr_read_asm(unsigned addr) {
 //     those of block 1: MFMAs under every vector stretch, K / V fragments of the whole tile held in registers, 212 VGPRs): 1.840 vs
 //     1.853 ms -- removed;
 //   * NW = 6 (192-row blocks, 384 threads, 166 VGPRs = three waves per SIMD, a third less K / V staging per query row): 2.116 vs
-//     1.844 ms (the 8 staging pieces do not divide over 6 waves and the barrier waits for the two that stage twice) -- kept only as
-//     AttnArgs.variant 2 for the A/B.
-// What did pay: the deferred running maximum below (1.869 -> 1.837 ms).
+//     1.844 ms (the 8 staging pieces do not divide over 6 waves and the barrier waits for the two that stage twice) -- not
+//     instantiated any more (the NW template parameter stays).
+//   * one 8-wave workgroup per CU with its two wave groups in ENFORCED anti-phase (an extra barrier for waves 4-7, two barriers per tile,
+//     ring of four slots: while one group is in its S^T MFMAs its SIMD partner is in exp2 / pair split): 1.963 vs 1.860 ms -- removed.
+// What these null results say, and tools/micro/mfma_valu_coexec.hip confirms in isolation: on this chip dense vector work beside dense MFMAs
+// is nearly ADDITIVE in time whichever wave it comes from (two waves per SIMD, 16 MFMAs + 96 v_fma per pair of iterations: 578 cycles
+// against 256 of matrix pipe and 384 of vector issue), so the lever is the NUMBER of vector instructions, not where they sit.
+// What did pay: the deferred running maximum (1.869 -> 1.837 ms) and the packed-f32 softmax below.
 template <bool CAUSAL, bool CAPTURE, int NW = 4>
 __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -108,6 +124,23 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
     ql[sub][1] = *reinterpret_cast<const half8*>(qp + a.q_lo + 32);
   }
   const float c_log2 = a.scale * LOG2E;
+  // PRE (every variant that captures nothing): the Q pairs are multiplied by scale * log2(e) ONCE and split again (q c = hi' + lo' to
+  // 2^-22), so the scores come out of the MFMAs in the log2 domain and the per-element multiply of the softmax disappears. The
+  // capture variant keeps the raw q (the hooks see q.k * scale with one rounding).
+  constexpr bool PRE = !CAPTURE;
+  if (PRE) {
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const HalfPair pr = split_pair(((float)qh[sub][ks][j] + (float)ql[sub][ks][j]) * c_log2);
+          qh[sub][ks][j] = pr.hi;
+          ql[sub][ks][j] = pr.lo;
+        }
+  }
+  const float cm = PRE ? 1.0f : c_log2;   // what turns a score difference into a log2 exponent
 
   int nk_eff = a.nk;
   if (CAUSAL) {
@@ -162,7 +195,17 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
     for (int dt = 0; dt < 4; ++dt)
       vaddr[dt] = lds_off_s(lds) + 2u * (unsigned)((4 * fg + qd) * 64 + (((2 * dt + (pd >> 1)) ^ swz) << 3) + 4 * (pd & 1));
   }
-  float m_run[2] = {-INFINITY, -INFINITY};  // running row maximum of the RAW scores
+  // per-lane byte addresses of the K fragment reads in ring slot 0, K hi tile (the K lo tile and the slot are added at the read):
+  // fragment (ks, t) = row t*16 + fr, 16-byte chunk (4 ks + fg) ^ swz128(row)
+  unsigned kaddr[2][4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = t * 16 + fr;
+      kaddr[ks][t] = lds_off_s(lds) + 2u * (unsigned)(r * 64 + (((ks * 4 + fg) ^ swz128(r)) << 3));
+    }
+  float m_run[2] = {-INFINITY, -INFINITY};  // running row maximum of the scores (raw, or in the log2 domain when PRE)
   float l_part[2] = {0.f, 0.f};             // this lane's share of the row sum (its 16 keys per tile), reduced at the end
 
   stage(0, 0);
@@ -171,38 +214,55 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
     __builtin_amdgcn_s_barrier();    // ... and everyone's; every wave has also finished reading the other slot (tile kt - 1)
     asm volatile("" ::: "memory");
     if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
-    const half_t* Kh = lds + (kt & 1) * (4 * TILE);
-    const half_t* Kl = Kh + TILE;
-
     // ---- S^T tile: st[sub][t][r] = S[q = fr (sub)][key = kt*64 + t*16 + 4*fg + r], three passes per 32-deep k step
     f32x4 st[2][4];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int t = 0; t < 4; ++t) st[s][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      // all sixteen K fragments of the tile are requested at once (inline asm: hipcc otherwise issues each compiler-visible read two to six
+      // MFMAs before its use behind an `s_waitcnt lgkmcnt(0)`, four exposed LDS latencies per tile); each group of MFMAs starts when its
+      // four have landed (LDS operations return in issue order: kl ks0, kh ks0, kl ks1, kh ks1)
+      constexpr int KLO = TILE * (int)sizeof(half_t);
+      const unsigned sbk = (unsigned)(kt & 1) * (unsigned)(4 * TILE * sizeof(half_t));
+      half8 kh[2][4], kl[2][4];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 kh[4], kl[4];
+      for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = t * 16 + fr;
-        const int off = r * 64 + (((ks * 4 + fg) ^ swz128(r)) << 3);
-        kh[t] = *reinterpret_cast<const half8*>(Kh + off);
-        kl[t] = *reinterpret_cast<const half8*>(Kl + off);
+        for (int t = 0; t < 4; ++t) kl[ks][t] = b128_read_asm<KLO>(kaddr[ks][t] + sbk);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) kh[ks][t] = b128_read_asm<0>(kaddr[ks][t] + sbk);
       }
       // the small terms first, the hi.hi product last
+      WCA_S_LGKM_WAIT4(12, kl[0][0], kl[0][1], kl[0][2], kl[0][3]);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[t], qh[s][ks], st[s][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[0][t], qh[s][0], st[s][t], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(8, kh[0][0], kh[0][1], kh[0][2], kh[0][3]);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], ql[s][ks], st[s][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[0][t], ql[s][0], st[s][t], 0, 0, 0);
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[t], qh[s][ks], st[s][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[0][t], qh[s][0], st[s][t], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(4, kl[1][0], kl[1][1], kl[1][2], kl[1][3]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl[1][t], qh[s][1], st[s][t], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(0, kh[1][0], kh[1][1], kh[1][2], kh[1][3]);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[1][t], ql[s][1], st[s][t], 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) st[s][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh[1][t], qh[s][1], st[s][t], 0, 0, 0);
     }
 
     if (CAPTURE) {
@@ -235,63 +295,70 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
             st[s][t][r] = dead ? -INFINITY : st[s][t][r];
           }
     }
+    // The vector work of a tile costs wall time even beside MFMAs (tools/micro/mfma_valu_coexec.hip: with two waves per SIMD a stream of
+    // 16 MFMAs + 96 plain vector instructions takes 0.9 x (pipe time + vector issue time)), so it is written on PAIRS of elements:
+    // v_max3, v_pk_add_f32, v_cvt_pk_f16_f32 -- 4.5 instructions per score for difference, exp2, pair split and row sum instead of 9.
     float mx[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      float m = st[s][0][0];
+      float m = fmaxf(fmaxf(st[s][0][0], st[s][0][1]), fmaxf(st[s][0][2], st[s][0][3]));
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) m = fmaxf(m, st[s][t][r]);
+      for (int t = 1; t < 4; ++t) {
+        m = fmaxf(fmaxf(m, st[s][t][0]), st[s][t][1]);   // v_max3_f32
+        m = fmaxf(fmaxf(m, st[s][t][2]), st[s][t][3]);
+      }
       mx[s] = xor32_maxf(xor16_maxf(m));
     }
     // DEFERRED running maximum (as in attention.hip): the reference point of a row is raised only when the tile maximum exceeds it
     // by more than 8 in the log2 domain (p <= 2^8: nowhere near the range of the f16 hi half, and p is carried as a pair anyway), or
     // when the first finite score of a row arrives. On random data SOME row of a wave grows its maximum in almost every tile, so the
     // undeferred branch (2 exp2 + 34 multiplies per lane) ran on nearly all of them.
-    const float thr_raw = 8.0f / c_log2;
+    const float thr_raw = 8.0f / cm;
     if (__any((mx[0] > m_run[0] + thr_raw) || (mx[1] > m_run[1] + thr_raw) || (m_run[0] == -INFINITY && mx[0] != -INFINITY) ||
               (m_run[1] == -INFINITY && mx[1] != -INFINITY))) {  // wave-uniform
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const float m_new = fmaxf(m_run[s], mx[s]);
-        const float alpha = (m_run[s] == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run[s] - m_new) * c_log2);  // m_new finite here
+        const float alpha = (m_run[s] == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f((m_run[s] - m_new) * cm);  // m_new finite here
         l_part[s] *= alpha;
 #pragma unroll
         for (int d = 0; d < 4; ++d) ot[s][d] *= alpha;
         m_run[s] = m_new;
       }
     }
-    // p = exp((s - m) * scale) as exp2(((s - m) * c)): the difference first (exact for nearby values), one rounding in the product
+    // p = exp2((s - m) cm): the difference first (exact for nearby values); P^T fragments (B operand of O^T = V^T P^T): k-step k2
+    // covers score tiles 2 k2, 2 k2 + 1, element j of the fragment = score (tile 2 k2 + (j >> 2), register j & 3)
     half8 ph[2][2], pl[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       const float mref = (m_run[s] == -INFINITY) ? 0.f : m_run[s];  // a row that has only seen masked keys: exp2(-inf) = 0
-      float psum = 0.f;
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f((st[s][t][r] - mref) * c_log2);
-          st[s][t][r] = p;
-          psum += p;
-        }
-      l_part[s] += psum;
-      // P^T fragments (B operand of O^T = V^T P^T): k-step k2 covers score tiles 2*k2, 2*k2+1
+      const f32x2 mm = f32x2{mref, mref};
+      f32x2 psum2 = f32x2{0.f, 0.f};
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        half8 fh, fl;
+        half2_ hh[4], ll[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const HalfPair p0 = split_pair(st[s][2 * k2][r]), p1 = split_pair(st[s][2 * k2 + 1][r]);
-          fh[r] = p0.hi;
-          fl[r] = p0.lo;
-          fh[4 + r] = p1.hi;
-          fl[4 + r] = p1.lo;
+        for (int u = 0; u < 4; ++u) {   // u -> (tile 2 k2 + (u >> 1), registers 2 (u & 1), 2 (u & 1) + 1)
+          const int t = 2 * k2 + (u >> 1), r0 = 2 * (u & 1);
+          f32x2 x = f32x2{st[s][t][r0], st[s][t][r0 + 1]} - mm;
+          if (!PRE) x = x * f32x2{cm, cm};
+          const f32x2 p = f32x2{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+          psum2 += p;
+          hh[u] = __builtin_convertvector(p, half2_);   // v_cvt_pk_f16_f32 (RNE)
+          // lo = f16(p - hi) by the mixed-precision fma (f32 p, f16 hi operand picked by op_sel; p - hi is exact before the one rounding):
+          // one instruction per element, no conversion back to f32, no packing (hipcc does not form it from the plain expression)
+          {
+            const unsigned hu = __builtin_bit_cast(unsigned, hh[u]);
+            unsigned lu;
+            asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(p[0]), "v"(hu));
+            asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(p[1]), "v"(hu));
+            ll[u] = __builtin_bit_cast(half2_, lu);
+          }
         }
-        ph[s][k2] = fh;
-        pl[s][k2] = fl;
+        ph[s][k2] = half8{hh[0][0], hh[0][1], hh[1][0], hh[1][1], hh[2][0], hh[2][1], hh[3][0], hh[3][1]};
+        pl[s][k2] = half8{ll[0][0], ll[0][1], ll[1][0], ll[1][1], ll[2][0], ll[2][1], ll[3][0], ll[3][1]};
       }
+      l_part[s] += psum2[0] + psum2[1];
     }
 
     // ---- O^T += V^T P^T. V^T fragment (A operand): lane holds V[key(k)][d = dt*16 + fr], k order matching the P fragments:
@@ -365,6 +432,7 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
 }
 
 
+
 }  // namespace
 
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
@@ -382,16 +450,10 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;                                                                                           \
     hipLaunchKernelGGL((attn_split_kernel<C, P, W>), dim3(((a.nq + (W) * 32 - 1) / ((W) * 32)) * a.H * a.B), dim3((W) * 64), shmem, s, a); \
   } while (0)
-  static const int env_variant = getenv("WCA_ATTN_SPLIT_VARIANT") ? atoi(getenv("WCA_ATTN_SPLIT_VARIANT")) : 0;  // 2: six waves on long rows (A/B)
-  const int variant = a.variant ? a.variant : env_variant;
   if (a.causal) {
     if (cap) WCA_LAUNCH_AS(true, true, 4); else WCA_LAUNCH_AS(true, false, 4);
-  } else if (cap) {
-    WCA_LAUNCH_AS(false, true, 4);
-  } else if (a.nq >= 768 && variant == 2) {  // experiment: 192-row workgroups, three waves per SIMD (slower: see the kernel's header)
-    WCA_LAUNCH_AS(false, false, 6);
   } else {
-    WCA_LAUNCH_AS(false, false, 4);
+    if (cap) WCA_LAUNCH_AS(false, true, 4); else WCA_LAUNCH_AS(false, false, 4);
   }
 #undef WCA_LAUNCH_AS
   return hipGetLastError();

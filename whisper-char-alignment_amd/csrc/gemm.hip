@@ -77,15 +77,22 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
       half_t* cp = reinterpret_cast<half_t*>(a.C) + coff + nb;
       if (full_n && ((reinterpret_cast<uintptr_t>(cp) & 15) == 0)) {
         half8 h0, h1, l0, l1;
+        if (OUT_MODE == 4) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (OUT_MODE == 4) {
-            const HalfPair p0 = split_pair(v[j]), p1 = split_pair(v[8 + j]);
-            h0[j] = p0.hi;
-            l0[j] = p0.lo;
-            h1[j] = p1.hi;
-            l1[j] = p1.lo;
-          } else {
+          for (int j = 0; j < 8; j += 2) {
+            const Half2Pair p0 = split_pair2(v[j], v[j + 1]), p1 = split_pair2(v[8 + j], v[8 + j + 1]);
+            h0[j] = p0.hi[0];
+            h0[j + 1] = p0.hi[1];
+            l0[j] = p0.lo[0];
+            l0[j + 1] = p0.lo[1];
+            h1[j] = p1.hi[0];
+            h1[j + 1] = p1.hi[1];
+            l1[j] = p1.lo[0];
+            l1[j + 1] = p1.lo[1];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
             h0[j] = (half_t)v[j];
             h1[j] = (half_t)v[8 + j];
           }

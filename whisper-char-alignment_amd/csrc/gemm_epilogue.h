@@ -109,15 +109,18 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           half8 o, ol;
+          if (OUT_MODE == 4) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (OUT_MODE == 4) {
-              const HalfPair pr = split_pair(v[hh * 8 + j]);
-              o[j] = pr.hi;
-              ol[j] = pr.lo;
-            } else {
-              o[j] = (half_t)v[hh * 8 + j];
+            for (int j = 0; j < 8; j += 2) {
+              const Half2Pair pr = split_pair2(v[hh * 8 + j], v[hh * 8 + j + 1]);
+              o[j] = pr.hi[0];
+              o[j + 1] = pr.hi[1];
+              ol[j] = pr.lo[0];
+              ol[j + 1] = pr.lo[1];
             }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)v[hh * 8 + j];
           }
           *reinterpret_cast<half8*>(cp + hh * 32 + fg * 8) = o;
           if (OUT_MODE == 4) *reinterpret_cast<half8*>(cp + a.c_lo + hh * 32 + fg * 8) = ol;  // lo halves (c_lo % 8 == 0: same alignment)

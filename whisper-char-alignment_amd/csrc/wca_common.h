@@ -99,6 +99,24 @@ __device__ __forceinline__ HalfPair split_pair(float x) {
   return r;
 }
 
+// Two values at once: hi = f16(x) by the packed RNE conversion (v_cvt_pk_f16_f32), lo = f16(x - hi) by the mixed-precision fma
+// (v_fma_mixlo / mixhi_f16: f32 x, f16 hi operand picked by op_sel; x - hi is exact before its one rounding) -- 3 vector instructions for two
+// elements where split_pair() costs 8 and a pack. Same values as split_pair(): the inputs are pinned first for the same reason.
+struct Half2Pair {
+  half2_ hi, lo;
+};
+__device__ __forceinline__ Half2Pair split_pair2(float x0, float x1) {
+  asm volatile("" : "+v"(x0), "+v"(x1));
+  Half2Pair r;
+  r.hi = __builtin_convertvector((f32x2{x0, x1}), half2_);
+  const unsigned hu = __builtin_bit_cast(unsigned, r.hi);
+  unsigned lu;
+  asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(x0), "v"(hu));
+  asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(x1), "v"(hu));
+  r.lo = __builtin_bit_cast(half2_, lu);
+  return r;
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: blocks that share an XCD
 // (id % 8 equal) get a contiguous range of logical ids, so neighbouring tiles hit one L2.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
