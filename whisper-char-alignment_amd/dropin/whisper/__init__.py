@@ -19,12 +19,15 @@ DecodingResult = _decoding.DecodingResult
 decode = _decoding.decode
 
 
-def load_model(name, device="cuda:0", download_root=None, in_memory=False, max_batch=8):
+def load_model(name, device="cuda:0", download_root=None, in_memory=False, max_batch=8, precision=None):
+    """whisper.load_model on the engine: the model runs the reference's fp32-equivalent forward (precision 'reference', the contract mode)
+    unless precision='f16' (or $WCA_PRECISION=f16) asks for the fast mode."""
     root = download_root or _os.environ.get("WCA_WEIGHTS_DIR") or _os.path.join(_os.path.expanduser("~"), ".cache", "whisper")
     path = name if _os.path.isfile(name) else _os.path.join(root, name + ".pt")
     if not _os.path.isfile(path):
         raise RuntimeError("no local checkpoint %s: this engine never downloads by model name (set WCA_WEIGHTS_DIR or pass download_root)" % path)
-    return _pkg.WhisperAMD.from_checkpoint(path, device=str(device), max_batch=max_batch, name=None if _os.path.isfile(name) else name)
+    return _pkg.WhisperAMD.from_checkpoint(path, device=str(device), max_batch=max_batch, name=None if _os.path.isfile(name) else name,
+                                           precision=precision or _os.environ.get("WCA_PRECISION", "reference"))
 
 
 audio = _types.ModuleType("whisper.audio")

@@ -240,15 +240,18 @@ class WhisperAMD:
         return self
 
     @classmethod
-    def from_checkpoint(cls, path, device="cuda:0", max_batch=8, name=None):
+    def from_checkpoint(cls, path, device="cuda:0", max_batch=8, name=None, precision="reference"):
         """Loads an openai-format checkpoint ({'dims':..., 'model_state_dict':...}) from a LOCAL path and, like
         whisper.load_model(name), installs the official alignment heads of `name` (inferred from the dimensions when
-        they identify the model; large-v1 / large-v2 need the name)."""
+        they identify the model; large-v1 / large-v2 need the name). This is the drop-in's `whisper.load_model`: the model comes
+        back in the CONTRACT precision mode ('reference': the fp32 forward of timing.py:58 to fp32 summation noise), unlike a bare
+        WhisperAMD(), which starts in the f16 fast mode; precision='f16' opts out."""
         ck = torch.load(path, map_location="cpu")
         dims = ModelDimensions(**ck["dims"])
         m = cls(dims, device=device, max_batch=max_batch)
         m.load_state_dict(ck["model_state_dict"])
         m.use_official_alignment_heads(name)
+        m.set_precision(precision)
         return m
 
     # ---- stream handling: always run on torch's current stream so torch tensors stay ordered
