@@ -313,6 +313,7 @@ AUDIO_TIME_PER_TOKEN = AUDIO_SAMPLES_PER_TOKEN / whisper.audio.SAMPLE_RATE
 DEVICE = 'cuda:0'
 model = whisper.load_model("tiny", download_root=%(wdir)r)
 model.to(DEVICE)
+assert model.precision == "split"   # the drop-in's load_model returns the CONTRACT mode (every site on operand pairs = the reference's fp32 forward)
 options = whisper.DecodingOptions(language="en")
 tokenizer = get_tokenizer(model.is_multilingual, language='English')
 audio = torch.from_numpy(np.load(%(pcm)r).astype(np.float32) / 32768.0)   # torchaudio.load(sample_audio) stand-in

@@ -139,6 +139,39 @@ def test_align_batch_matches_stepwise_api(wca, setup):
         assert (w1 - w).abs().max().item() < 1e-3
 
 
+def test_cu_partition_changes_nothing_but_the_streams(wca, setup):
+    """wca_set_cu_partition (the co-scheduling experiment, profiles/r04_cu_partition.txt): phase 2 on CU-masked streams owning 64 CUs,
+    phase 1 on the rest with its persistent GEMM grids sized to match -- the results must be those of the unpartitioned engine bit for
+    bit (same kernels, same arithmetic, another workgroup -> tile walk), two batches in flight included; 0 lifts it; bad sizes are refused."""
+    syn, tk, rt, tm, audio = _mods()
+    dims, sd, model, tok = setup
+    specs = [(41, 48000, 25), (42, 80000, 40), (43, 32000, 12)]
+    utts = [_utt(syn, rt, tok, u, n, c) for u, n, c in specs]
+    n_max, smax = max(len(u[3]) for u in utts), max(len(u[0]) for u in utts)
+    pcm = np.zeros((3, smax), dtype=np.float32)
+    tarr = np.full((3, n_max), tok.eot, dtype=np.int64)
+    for i, (p, _, _, toks) in enumerate(utts):
+        pcm[i, :len(p)] = p
+        tarr[i, :len(toks)] = toks
+    args = (torch.from_numpy(pcm).cuda(), [len(u[0]) for u in utts], torch.from_numpy(tarr).cuda(), [len(u[3]) for u in utts],
+            [len(u[0]) // 320 for u in utts], model.make_opts(aggregation="topk", topk=4, sot_len=3, medfilt_width=3))
+    jump0, sel0 = model.align_batch(*args)
+    try:
+        model.set_cu_partition(64)
+        jump1, sel1 = model.align_batch(*args)
+        model.align_batch(*args, enqueue_only=True)      # two in flight on the masked streams
+        model.align_batch(*args, enqueue_only=True)
+        j2, s2 = model.fetch(3, n_max, args[5])
+        j3, s3 = model.fetch(3, n_max, args[5])
+        with pytest.raises(RuntimeError):
+            model.set_cu_partition(65)                    # a multiple of 8 below the CU count
+    finally:
+        model.set_cu_partition(0)
+    jump4, sel4 = model.align_batch(*args)
+    for j, s_ in ((jump1, sel1), (j2, s2), (j3, s3), (jump4, sel4)):
+        assert np.array_equal(j, jump0) and np.array_equal(s_, sel0)
+
+
 def test_too_long_is_rejected(wca, setup):
     syn, tk, rt, tm, audio = _mods()
     dims, sd, model, tok = setup
