@@ -46,7 +46,8 @@ def oracle_word_times(args, sd, dims, syn, audio_mod, ids):
     key = "oracle_%s_peaky008_s%d_c%d_k%d_m%d_ids%d-%d" % (args.model, int(args.seconds), args.chars, args.topk, args.medfilt_width, ids[0], ids[-1])
     gold = os.path.join(ROOT, "tests", "golden", "oracle_word_times_medium_peaky.npz")   # tests/golden/make_oracle_word_times.py
     standard = (args.model, int(args.seconds), args.chars, args.topk, args.medfilt_width) == ("medium", 10, 64, 10, 3)
-    for path in ([gold] if standard else []) + [os.path.join(ROOT, "gpurun_out", key + ".npz")]:
+    # (tools/cache/ is git-ignored but travels to the GPU box: a cache computed with --oracle-only in the build container goes there)
+    for path in ([gold] if standard else []) + [os.path.join(ROOT, "tools", "cache", key + ".npz"), os.path.join(ROOT, "gpurun_out", key + ".npz")]:
         if os.path.exists(path):
             z = np.load(path, allow_pickle=False)
             if all("st_%d" % u in z.files for u in ids):
