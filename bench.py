@@ -664,8 +664,8 @@ def main():
                                    % (args.model, args.seconds, args.chars, args.topk, args.medfilt_width, len(batches) * args.batch),
                        "precision": args.precision + (" (operands rounded to f16 once, fp32 accumulate: the fast mode, NOT the contract line)" if args.precision == "f16" else
                                                       " (wca_set_precision(WCA_PRECISION_REFERENCE = SPLIT): sites %s on (hi, lo) operand pairs -- pair GEMMs with every "
-                                                      "W K-tile staged once, three-pass attention; 6 184 / 6 184 boundaries identical to the fp32 CPU oracle on the "
-                                                      "301-utterance leg and selection scores within 4e-6, profiles/r04_precision_ablation.txt; achieved / frac count "
+                                                      "W K-tile staged once, three-pass attention; 20 418 / 20 418 boundaries identical to the fp32 CPU oracle on the 301- and "
+                                                      "700-utterance legs, selection scores within 4e-6 (profiles/r04_precision_ablation.txt, r04_parity_leg_700utt.txt); achieved / frac count "
                                                       "ALGORITHMIC flops, the MFMA pipe executes 2x (GEMM) / 3x (attention) of them; the f16-operand mode of the same run is "
                                                       "under `f16_operating_point`)" % "+".join(model.precision_sites[0])),
                        "engine_defaults": "every engine setting is the shipped default except the precision mode named above (LayerNorms as separate launches"

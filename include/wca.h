@@ -375,7 +375,8 @@ int wca_set_fuse_ln(wca_engine* e, int on);
  *     shows that nothing from the encoder blocks on can be left on single f16 operands: every smaller site set misses at least one
  *     utterance whose 10th / 11th oracle head scores are within 5e-5 of each other. Leaving only the log-mel and the conv stem on
  *     single operands changes no boundary on that leg and costs 1 % less, but moves the selection scores by 1e-4 relative
- *     (all sites split: 4e-6) -- 2x the smallest score gap on the leg -- so it passes there without margin and is not the contract. */
+ *     (all sites split: 4e-6), and on a second leg of 700 utterances (profiles/r04_parity_leg_700utt.txt) it misses two utterances
+ *     whose oracle scores are tied to 1e-5 while all sites give 14 234 / 14 234 boundaries identical: it is not the contract. */
 enum { WCA_PRECISION_F16 = 0, WCA_PRECISION_SPLIT = 1, WCA_PRECISION_REFERENCE = 1, WCA_PRECISION_MIXED = 2 };
 int wca_set_precision(wca_engine* e, int mode);   /* F16 or SPLIT (= REFERENCE) */
 int wca_get_precision(wca_engine* e);  /* F16: no site is split; SPLIT: every site; MIXED: some (wca_get_precision_sites) */
