@@ -419,3 +419,38 @@ def test_precision_sites_seams_small_dims(wca):
     model.set_precision("f16")
     assert torch.equal(maps(), w_f16)
     del model
+
+
+def test_failed_precision_switch_leaves_a_working_engine(wca, monkeypatch):
+    """wca_set_precision allocates the NEW arena (and the K-doubled weight copies) before it releases the old ones and
+    commits the mode only when both allocations succeeded. With an allocation failure injected (WCA_TEST_FAIL_PRECISION_ALLOC) the switch
+    must return WCA_ERR_HIP, the engine must stay in its previous mode with every arena pointer intact -- same maps bit for bit -- and a
+    later switch must work; the same from the split mode back to f16."""
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 2, 51865, 448, 256, 4, 2)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2).load_state_dict(syn.random_state_dict(dims, seed=9, cross_qk_std=0.08))
+    tok = tk.get_tokenizer(True, language="English")
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 3, 64000, 30)
+    mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+    tdev = torch.tensor(tokens).cuda()
+
+    def maps():
+        return tm.get_attentions(mel, tdev, model, tok, 200, medfilt_width=3)[0].cpu()
+
+    w16 = maps()
+    monkeypatch.setenv("WCA_TEST_FAIL_PRECISION_ALLOC", "1")
+    with pytest.raises(wca._lib.WcaError, match="keeps its previous mode"):
+        model.set_precision("split")
+    assert model.precision == "f16" and torch.equal(maps(), w16)
+    monkeypatch.delenv("WCA_TEST_FAIL_PRECISION_ALLOC")
+    model.set_precision("split")
+    wsp = maps()
+    assert model.precision == "split" and (wsp - w16).abs().max().item() < 1e-2 and not torch.equal(wsp, w16)
+    monkeypatch.setenv("WCA_TEST_FAIL_PRECISION_ALLOC", "1")
+    with pytest.raises(wca._lib.WcaError, match="keeps its previous mode"):
+        model.set_precision("f16")
+    assert model.precision == "split" and torch.equal(maps(), wsp)
+    monkeypatch.delenv("WCA_TEST_FAIL_PRECISION_ALLOC")
+    model.set_precision("f16")
+    assert torch.equal(maps(), w16)
+    del model

@@ -1541,6 +1541,7 @@ int wca_set_precision_sites(wca_engine* e, unsigned mask, int enc_first_layer) {
     }
     if (he == hipSuccess) he = hipMemset(na, 0, abytes);  // zero pad rows of mel_tm / h1pad, counters, flags and all slack
     if (he == hipSuccess && nw) he = hipMemset(nw, 0, wbytes);  // K padding of the conv1 copy stays zero
+    if (he == hipSuccess && std::getenv("WCA_TEST_FAIL_PRECISION_ALLOC")) he = hipErrorOutOfMemory;  // fault injection for the test of the path below
     if (he != hipSuccess) {
       if (na) (void)hipFree(na);
       if (nw) (void)hipFree(nw);
