@@ -492,3 +492,40 @@ def test_force_align_subword_mode(wca, fake_vocab):
     assert len(st) == len(words) - 1
     assert np.max(np.abs(np.asarray(st) - np.asarray(rst))) <= 0.02 + 1e-9
     assert np.max(np.abs(np.asarray(en) - np.asarray(ren))) <= 0.02 + 1e-9
+
+
+def test_head_stats_lean_kernel_changes_no_bit_of_the_alignment(wca, monkeypatch):
+    """The fused path (capture -> head statistics -> top-k -> aggregation -> DTW) with the lean head-statistics kernel against the general one
+    (WCA_HEAD_STATS_GENERAL=1): selected heads in score order and jump frames identical, in both precision modes and for ragged lengths (the
+    aggregation re-materialises the selected heads with the general kernel's arithmetic: row maxima and sums must agree exactly), and the
+    step-by-step API's weights bit for bit."""
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=8).load_state_dict(syn.random_state_dict(dims, seed=4, cross_qk_std=0.08))
+    tok = tk.get_tokenizer(True, language="English")
+    utts = [_utt(syn, rt, tok, 700 + i, 40000 + 23000 * i, 20 + 7 * i) for i in range(8)]
+    n_max, smax = max(len(u[3]) for u in utts), max(len(u[0]) for u in utts)
+    pcm = np.zeros((8, smax), dtype=np.float32)
+    tarr = np.full((8, n_max), tok.eot, dtype=np.int64)
+    for i, (p, _, _, toks) in enumerate(utts):
+        pcm[i, :len(p)] = p
+        tarr[i, :len(toks)] = toks
+    n_samples, n_tok, frames = [len(u[0]) for u in utts], [len(u[3]) for u in utts], [len(u[0]) // 320 for u in utts]
+    pcm_d, tarr_d = torch.from_numpy(pcm).cuda(), torch.from_numpy(tarr).cuda()
+    for mode in ("f16", "reference"):
+        model.set_precision(mode)
+        for w in (3, 7):
+            opts = model.make_opts(aggregation="topk", topk=5, sot_len=3, medfilt_width=w)
+            monkeypatch.setenv("WCA_HEAD_STATS_GENERAL", "1")
+            jump0, sel0 = model.align_batch(pcm_d, n_samples, tarr_d, n_tok, frames, opts)
+            mel = model.log_mel(pcm_d, n_samples)
+            wb0, _ = model.get_attentions(mel, tarr_d, frames, medfilt_width=w, n_tok=n_tok, want_logits=False)
+            wb0 = wb0.clone()
+            monkeypatch.delenv("WCA_HEAD_STATS_GENERAL")
+            jump1, sel1 = model.align_batch(pcm_d, n_samples, tarr_d, n_tok, frames, opts)
+            wb1, _ = model.get_attentions(mel, tarr_d, frames, medfilt_width=w, n_tok=n_tok, want_logits=False)
+            assert np.array_equal(sel0, sel1) and np.array_equal(jump0, jump1), (mode, w)
+            for i in range(8):
+                a, b = wb0[i, :, :, :n_tok[i], :frames[i]], wb1[i, :, :, :n_tok[i], :frames[i]]
+                assert torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32)), (mode, w, i)
+    del model

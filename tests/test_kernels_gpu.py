@@ -614,3 +614,39 @@ def test_logmel_full_length_and_sample(eng, wca):
         got = eng.log_mel(torch.from_numpy(pcm).cuda()).cpu()
         ref = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), filt)
         assert (got - ref).abs().max().item() < 2e-4
+
+
+# ------------------------------------------------------------------------------- head statistics: lean kernel == general kernel
+@pytest.mark.parametrize("w", [1, 3, 5, 7, 9])
+@pytest.mark.parametrize("n,S,F", [(1, 1, 1), (3, 2, 2), (5, 70, 3), (4, 64, 63), (7, 64, 64), (6, 130, 65), (70, 512, 500), (9, 777, 777),
+                                   (11, 1500, 1024), (5, 1500, 1500)])
+def test_head_stats_lean_kernel_bit_identical_to_general(eng, wca, monkeypatch, w, n, S, F):
+    """`head_stats_fast_kernel` (postproc.hip: packed-f32 libm expf sequence, row-shared reciprocal refinement of the IEEE division, v_med3
+    medians, no exec masking) must give the bits of the general kernel on every element: logits of wide dynamic range (rows whose smallest
+    exponent argument lies below -68 take the plain-division branch, rows with -inf and with a 1e4 outlier included), every unrolled filter
+    width, frame counts on both sides of the 64-lane groups, tight rows (S == F: clamped loads) and padded rows."""
+    tm = importlib.import_module("whisper-char-alignment_amd.timing")
+    g = torch.Generator().manual_seed(1000 * w + 10 * n + F)
+    qk = torch.randn(2, 3, n, S, generator=g) * 4.0
+    qk[0, 1] *= 8.0                       # x down to ~ -200: underflow arm, plain-division rows
+    qk[1, 0] *= 0.05                      # near-uniform rows
+    if S > 4:
+        qk[1, 1, 0, 1] = float("-inf")
+        qk[1, 2, n - 1, S // 2] = 1.0e4
+    scale = 0.37
+    if S >= 64 and n >= 3:                # exponent arguments sweeping through the branch threshold (-68) and the underflow bound (-103.3)
+        qk[0, 2, 0] = torch.linspace(0, -110 / scale, S)
+        qk[0, 2, 1] = torch.linspace(0, -67.9 / scale, S)
+        qk[0, 2, 2] = torch.linspace(-72 / scale, 0, S)
+    qk = qk.cuda()
+    monkeypatch.setenv("WCA_HEAD_STATS_GENERAL", "1")
+    ref = tm.attention_weights(qk, F, medfilt_width=w, qk_scale=scale).cpu()
+    monkeypatch.delenv("WCA_HEAD_STATS_GENERAL")
+    out = tm.attention_weights(qk, F, medfilt_width=w, qk_scale=scale).cpu()
+    assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (out - ref).abs().max().item()
+    # and both are the softmax they claim to be
+    x = qk.cpu()[..., :F]
+    if w > 1 and F > w // 2:
+        x = torch.nn.functional.pad(x.reshape(1, -1, F), (w // 2, w // 2), mode="reflect").unfold(-1, w, 1).sort(-1)[0][..., w // 2].reshape(x.shape)
+    want = torch.softmax(x.double() * scale, -1)
+    assert (out.double() - want).abs().max().item() < 2e-6

@@ -5,6 +5,7 @@
 //   topk       : ascending top-k heads in python tuple order (score, (l,h))            timing.py:36
 //   aggregate  : mean over selected heads of A / ||A||_col                              timing.py:84-97
 //   median_filter : standalone whisper.timing.median_filter
+#include <cstdlib>
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -222,6 +223,309 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// head_stats_fast_kernel: the SAME arithmetic as head_stats_kernel, bit for bit (tests/test_postproc_gpu.py compares the two on every
+// output), written for the vector-instruction budget: the general kernel above is bound by vector issue, not by HBM (2.9 TB/s: ~45 vector
+// instructions and 5 exec-mask branches per logit). Here, for filter widths 1 / 3 / 5 / 7 / 9 and logits as input:
+//   * no exec masking in the row loop: column offsets are clamped to F - 1 (every load is in bounds), lanes past F are set to -inf by ONE
+//     v_cndmask after the median (their LDS garbage reaches no valid column: the reflect halo is written after the row);
+//   * rows are addressed by a scalar base (wave index through readfirstlane) + a per-lane column offset: no 64-bit vector address math;
+//   * the median of 3 is v_med3_f32 on (LDS left, register centre, LDS right), of 5 the 7-operation min / max / med3 form -- a median is
+//     one of its inputs, so any correct selection gives the same bits as the sorting network of median_w;
+//   * expf: libm's own sequence (ph = x log2e, pl its rounding error + x log2e_lo, e = rint(ph), ldexp(exp2((ph - e) + pl), e), 0 below
+//     -103.28) on PAIRS of elements (v_pk_mul / v_pk_fma / v_pk_add_f32) without its overflow arm (x = v - max <= 0);
+//   * p = e / sum: the reciprocal refinement of the IEEE division expansion depends on the row sum only -- done once per row; per element the
+//     five remaining steps q0 = n r, e1 = fma(-d, q0, n), q1 = fma(e1, r, q0), e2 = fma(-d, q1, n), q = fma(e2, r, q1) as packed operations.
+//     That IS v_div_scale / v_div_fmas / v_div_fixup's result whenever no operand scaling triggers (sum in [1, 1536]: numerator >= 2^-100
+//     or 0); a row holding a smaller non-zero numerator (x < -68 on a valid column) takes the plain `/` instead;
+//   * wave reductions with the DPP operand folded into the add / max (same summation tree as wave_sum).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float vmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float vmax3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmin3_raw(float a, float b, float c) {
+  float r;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float vmed3_raw(float a, float b, float c) {
+  float r;
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// wave_sum's tree (v += ror 1, 2, 4, 8 inside rows of 16, then the 16- and 32-lane swaps) with the rotate folded into the add
+__device__ __forceinline__ float wave_sum_folded(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(v));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float wave_max_folded(float v) {
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+      : "+v"(v));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+// median of the W values centred on p[0] (LDS), `c` = p[0] already in a register
+template <int W>
+__device__ __forceinline__ float median_centre(const float* p, float c) {
+  if (W == 1) return c;
+  if (W == 3) return vmed3_raw(p[-1], c, p[1]);
+  if (W == 5) {
+    const float a = p[-2], b = p[-1], d = p[1], e = p[2];
+    const float lo = vmax_raw(vmin_raw(a, b), vmin_raw(d, e)), hi = vmin_raw(vmax_raw(a, b), vmax_raw(d, e));
+    return vmed3_raw(c, lo, hi);
+  }
+  return median_w<W>(p - (W >> 1));
+}
+
+// expf(x) for x <= 0 (or NaN): the instruction sequence of the device libm's expf on two elements, overflow arm dropped
+__device__ __forceinline__ f32x2 expf_nonpos2(f32x2 x) {
+  const float L2E = __uint_as_float(0x3fb8aa3bu), L2E_LO = __uint_as_float(0x32a5705fu), UNDER = __uint_as_float(0xc2ce8ed0u);
+  f32x2 ph = x * L2E;
+  asm volatile("" : "+v"(ph));  // no contraction of this product into the subtractions below
+  f32x2 pl = __builtin_elementwise_fma(x, (f32x2){L2E, L2E}, -ph);
+  pl = __builtin_elementwise_fma(x, (f32x2){L2E_LO, L2E_LO}, pl);
+  const f32x2 e = {__builtin_rintf(ph.x), __builtin_rintf(ph.y)};
+  f32x2 a = ph - e;
+  asm volatile("" : "+v"(a));
+  a = a + pl;
+  f32x2 r;
+  r.x = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a.x), (int)e.x);
+  r.y = __builtin_amdgcn_ldexpf(__builtin_amdgcn_exp2f(a.y), (int)e.y);
+  r.x = (UNDER > x.x) ? 0.f : r.x;
+  r.y = (UNDER > x.y) ? 0.f : r.y;
+  return r;
+}
+
+template <int NPL, int W>
+__global__ __launch_bounds__(256) void head_stats_fast_kernel(HeadStatsArgs a) {
+  static_assert(NPL % 2 == 0, "pairs of elements");
+  constexpr int NP = NPL / 2;
+  constexpr int RB = 64 * NPL + 2 * HALO;        // every lane slot of a row has an LDS word (lanes past F write garbage there)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sm = reinterpret_cast<float*>(smem);
+  const int Fmax = a.n_frames_max;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* rowbuf = sm + wave * RB;
+  float* red_sq = sm + 4 * RB;                   // [4][Fmax]
+  float* red_sum = red_sq + 4 * Fmax;            // [4][Fmax]
+  float* red_scalar = red_sum + 4 * Fmax;        // [16]
+
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int n = a.n_tok[b], F = a.n_frames[b];
+  constexpr int pad = W >> 1;
+  const bool do_med = (W > 1) && (F > pad);
+  const float* qk = a.qk + (long)b * a.qk_bs + (long)head * a.qk_hs;
+  float* wout = a.weights ? a.weights + (long)b * a.w_bs + (long)head * a.n_tok_max * Fmax : nullptr;
+  float* rsp = a.rowstats ? a.rowstats + ((long)b * a.LH + head) * a.n_tok_max * 2 : nullptr;
+  const float scale = a.qk_scale;
+
+  // rows through a buffer descriptor on this head's block: scalar row offset + 32-bit vector column offset, no vector address arithmetic
+  const int row_bytes = a.qk_ld * 4;
+  const long head_bytes = n > 0 && F > 0 ? ((long)(n - 1) * a.qk_ld + F) * 4 : 0;
+  const __amdgpu_buffer_rsrc_t rq =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qk), 0, (int)(head_bytes < 0x7fffffffL ? head_bytes : 0x7fffffffL), 0x00020000);
+  unsigned colofs[NPL];   // BYTE offset of the lane's column, clamped into the row: scalar row base + 32-bit vector offset addressing
+  bool valid[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = lane + 64 * i;
+    valid[i] = f < F;
+    colofs[i] = 4u * (unsigned)max(min(f, F - 1), 0);
+  }
+  f32x2 csq[NP], csum[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    csq[j] = (f32x2){0.f, 0.f};
+    csum[j] = (f32x2){0.f, 0.f};
+  }
+  float rown_acc = 0.f;
+
+  float nxt[NPL];
+  if (wave < n && F > 0) {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) nxt[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, (int)colofs[i], wave * row_bytes, 0));
+  } else {
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) nxt[i] = 0.f;
+  }
+  if (F <= 0) {  // no frames: what the masked form leaves behind (row maximum -inf, sum 0, nothing accumulated)
+    if (rsp && lane == 0)
+      for (int t = wave; t < n; t += 4) {
+        rsp[2 * t] = -INFINITY;
+        rsp[2 * t + 1] = 0.f;
+      }
+  }
+  for (int t = wave; t < n && F > 0; t += 4) {
+    float v[NPL];
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) v[i] = nxt[i];
+    if (t + 4 < n) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) nxt[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rq, (int)colofs[i], (t + 4) * row_bytes, 0));
+    }
+    if (do_med) {
+#pragma unroll
+      for (int i = 0; i < NPL; ++i) rowbuf[HALO + lane + 64 * i] = v[i];
+      __builtin_amdgcn_wave_barrier();
+      if (lane < pad) {
+        const int k = lane + 1;
+        rowbuf[HALO - k] = rowbuf[HALO + k];
+        rowbuf[HALO + F - 1 + k] = rowbuf[HALO + F - 1 - k];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (W == 3) {  // all neighbour reads in flight before the first median
+        float lf[NPL], rt[NPL];
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) {
+          lf[i] = rowbuf[HALO + lane + 64 * i - 1];
+          rt[i] = rowbuf[HALO + lane + 64 * i + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] = __builtin_amdgcn_fmed3f(lf[i], v[i], rt[i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NPL; ++i) v[i] = median_centre<W>(rowbuf + HALO + lane + 64 * i, v[i]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // scale; lanes past F -> -inf; row maximum and (over the finite values, garbage lanes included: conservative) row minimum
+    f32x2 s2[NP];
+    float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      f32x2 sv = (f32x2){v[2 * j], v[2 * j + 1]} * scale;
+      mn = vmin3_raw(mn, sv.x, sv.y);
+      sv.x = valid[2 * j] ? sv.x : -INFINITY;
+      sv.y = valid[2 * j + 1] ? sv.y : -INFINITY;
+      mx = vmax3_raw(mx, sv.x, sv.y);
+      s2[j] = sv;
+    }
+    mx = wave_max_folded(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      s2[j] = expf_nonpos2(s2[j] - mx);
+      sum += s2[j].x;
+      sum += s2[j].y;
+    }
+    sum = wave_sum_folded(sum);
+    if (rsp && lane == 0) {
+      rsp[2 * t] = mx;
+      rsp[2 * t + 1] = sum;
+    }
+    // a non-zero numerator below 2^-100 makes the IEEE expansion scale its operands: those rows divide the plain way
+    const bool tiny = __builtin_amdgcn_ballot_w64(mn - mx < -68.0f) != 0;
+    float rsq = 0.f;
+    if (!tiny) {
+      const float r0 = __builtin_amdgcn_rcpf(sum);
+      const float e0 = __builtin_fmaf(-sum, r0, 1.0f);
+      const float r1 = __builtin_fmaf(e0, r0, r0);
+      const f32x2 nd = {-sum, -sum}, rr = {r1, r1};
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const f32x2 nn = s2[j];
+        f32x2 q = nn * rr;
+        asm volatile("" : "+v"(q));
+        f32x2 er = __builtin_elementwise_fma(nd, q, nn);
+        q = __builtin_elementwise_fma(er, rr, q);
+        er = __builtin_elementwise_fma(nd, q, nn);
+        q = __builtin_elementwise_fma(er, rr, q);
+        s2[j] = q;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        s2[j].x = s2[j].x / sum;
+        s2[j].y = s2[j].y / sum;
+      }
+    }
+    if (wout) {
+      float* wrow = wout + (long)t * Fmax;
+#pragma unroll
+      for (int i = 0; i < NPL; ++i)
+        if (valid[i]) wrow[lane + 64 * i] = (i & 1) ? s2[i >> 1].y : s2[i >> 1].x;
+    }
+    // lanes past F hold p = 0 (expf(-inf) = 0, 0 / sum = 0): they add nothing below, exactly like the masked form
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const f32x2 p = s2[j];
+      rsq = __builtin_fmaf(p.x, p.x, rsq);
+      rsq = __builtin_fmaf(p.y, p.y, rsq);
+      csq[j] = __builtin_elementwise_fma(p, p, csq[j]);
+      csum[j] = csum[j] + p;
+    }
+    rown_acc += sqrtf(wave_sum_folded(rsq));
+  }
+
+  // ---- deterministic cross-wave reduction of the per-column statistics (as in head_stats_kernel)
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int f = lane + 64 * i;
+    if (f < F) {
+      red_sq[wave * Fmax + f] = (i & 1) ? csq[i >> 1].y : csq[i >> 1].x;
+      red_sum[wave * Fmax + f] = (i & 1) ? csum[i >> 1].y : csum[i >> 1].x;
+    }
+  }
+  if (lane == 0) red_scalar[wave] = rown_acc;
+  __syncthreads();
+  float cn_part = 0.f, cov_part = 0.f;
+  float* cn_out = a.colnorm + ((long)b * a.LH + head) * Fmax;
+  for (int f = tid; f < F; f += 256) {
+    const float sq = ((red_sq[f] + red_sq[Fmax + f]) + red_sq[2 * Fmax + f]) + red_sq[3 * Fmax + f];
+    const float sm_ = ((red_sum[f] + red_sum[Fmax + f]) + red_sum[2 * Fmax + f]) + red_sum[3 * Fmax + f];
+    const float cn = sqrtf(sq);
+    cn_out[f] = cn;
+    cn_part += cn;
+    cov_part += fmaxf(sm_, 0.5f);
+  }
+  cn_part = wave_sum(cn_part);
+  cov_part = wave_sum(cov_part);
+  if (lane == 0) {
+    red_scalar[4 + wave] = cn_part;
+    red_scalar[8 + wave] = cov_part;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float rown = ((red_scalar[0] + red_scalar[1]) + red_scalar[2]) + red_scalar[3];
+    const float coln = ((red_scalar[4] + red_scalar[5]) + red_scalar[6]) + red_scalar[7];
+    const float cov = (((red_scalar[8] + red_scalar[9]) + red_scalar[10]) + red_scalar[11]) - 0.5f * (float)F;
+    float score = 0.f;
+    if (a.w_col > 0.f) score += a.w_col * coln;
+    if (a.w_row > 0.f) score += a.w_row * rown;
+    if (a.w_cov > 0.f) score -= a.w_cov * cov;
+    a.scores[(long)b * a.LH + head] = score;
+  }
+}
+
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ scores, int LH, int k, int* __restrict__ sel_idx,
                                                    float* __restrict__ sel_score) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -388,8 +692,34 @@ hipError_t launch_head_stats(const HeadStatsArgs& a, hipStream_t s) {
   if (a.n_frames_max <= 0 || a.n_frames_max > 64 * MAX_NPL) return hipErrorInvalidValue;
   if (a.medfilt_width < 1 || (a.medfilt_width & 1) == 0 || (a.medfilt_width >> 1) > HALO) return hipErrorInvalidValue;
   const int Fmax = a.n_frames_max;
-  const size_t shmem = sizeof(float) * (4 * (size_t)(Fmax + 2 * HALO) + 8 * (size_t)Fmax + 16);
   dim3 grid(a.LH, a.B), block(256);
+  const int w = a.medfilt_width;
+  // the instruction-lean kernel (same bits) for logits input and the unrolled filter widths; WCA_HEAD_STATS_GENERAL=1 keeps the general one (A/B, tests)
+  if (!a.input_is_weights && w <= 9 && !std::getenv("WCA_HEAD_STATS_GENERAL")) {
+#define WCA_HSF(NPL, W)                                                                                   \
+  do {                                                                                                    \
+    const size_t shm = sizeof(float) * (4 * (size_t)(64 * NPL + 2 * HALO) + 8 * (size_t)Fmax + 16);      \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_stats_fast_kernel<NPL, W>),     \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);             \
+    if (e != hipSuccess) return e;                                                                        \
+    hipLaunchKernelGGL((head_stats_fast_kernel<NPL, W>), grid, block, shm, s, a);                         \
+    return hipGetLastError();                                                                             \
+  } while (0)
+#define WCA_HSF_W(NPL)                     \
+  switch (w) {                             \
+    case 1: WCA_HSF(NPL, 1);               \
+    case 3: WCA_HSF(NPL, 3);               \
+    case 5: WCA_HSF(NPL, 5);               \
+    case 7: WCA_HSF(NPL, 7);               \
+    default: WCA_HSF(NPL, 9);              \
+  }
+    if (Fmax <= 64 * 8) { WCA_HSF_W(8); }
+    else if (Fmax <= 64 * 16) { WCA_HSF_W(16); }
+    else { WCA_HSF_W(24); }
+#undef WCA_HSF_W
+#undef WCA_HSF
+  }
+  const size_t shmem = sizeof(float) * (4 * (size_t)(Fmax + 2 * HALO) + 8 * (size_t)Fmax + 16);
 #define WCA_HS(NPL)                                                                                \
   do {                                                                                             \
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_stats_kernel<NPL>),      \
