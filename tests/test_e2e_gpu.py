@@ -529,3 +529,61 @@ def test_head_stats_lean_kernel_changes_no_bit_of_the_alignment(wca, monkeypatch
                 a, b = wb0[i, :, :, :n_tok[i], :frames[i]], wb1[i, :, :, :n_tok[i], :frames[i]]
                 assert torch.equal(a.contiguous().view(torch.int32), b.contiguous().view(torch.int32)), (mode, w, i)
     del model
+
+
+def test_contract_mode_parity_ragged_lengths(wca):
+    """The contract mode on RAGGED micro-batches at whisper-medium dims: 64 utterances of 2-29 s audio and 9-220 characters (ids 20000-20063
+    of tools/parity_ragged.py's leg A: north-star settings -- char units, topk 10, medfilt 3 -- but a different frame count, decoder length
+    and reflect-padding position per utterance) through the fused wca_align_batch at B = 32: every word boundary within one frame of the
+    fp32 CPU oracle's (measured: all identical; the f16 operating point misses 3 of the leg's 128 utterances). Oracle word times from
+    tests/golden/oracle_word_times_ragged_A.npz (`python tools/parity_ragged.py --leg A --oracle-only`, then copied from tools/cache/);
+    the live oracle re-derives the shortest utterance of the batch and must reproduce the fixture."""
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_ragged
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=32).load_state_dict(sd)
+    model.set_precision("reference")
+    tok = tk.get_tokenizer(True, language="English")
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_word_times_ragged_A.npz"))
+    opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
+    ids = list(range(20000, 20064))
+    total = within = 0
+    offenders = []
+    for lo in range(0, 64, 32):
+        chunk = ids[lo:lo + 32]
+        sp = [parity_ragged.spec(u) for u in chunk]
+        pcm = np.zeros((32, max(s for s, _ in sp)), dtype=np.float32)
+        tts = []
+        for j, (u, (ns, ch)) in enumerate(zip(chunk, sp)):
+            pcm[j, :ns] = syn.synth_audio(u, ns)
+            tts.append(rt.encode(syn.synth_text(u, ch), tok, "char"))
+        rows = [[*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot] for tt in tts]
+        tarr = np.full((32, max(len(r) for r in rows)), tok.eot, dtype=np.int64)
+        for j, r in enumerate(rows):
+            tarr[j, :len(r)] = r
+        jump, _ = model.align_batch(torch.from_numpy(pcm).cuda(), [s for s, _ in sp], torch.from_numpy(tarr).cuda(), [len(r) for r in rows],
+                                    [s // 320 for s, _ in sp], opts)
+        for j, u in enumerate(chunk):
+            _w, st, en = tm.words_from_jump_frames(jump[j], tts[j], tok, "char")
+            d = np.concatenate([np.abs(np.asarray(st) - gold["st_%d" % u]), np.abs(np.asarray(en) - gold["en_%d" % u])])
+            total += d.size
+            within += int((d <= 0.02 + 1e-9).sum())
+            if (d > 0.02 + 1e-9).any():
+                offenders.append(u)
+    print("contract mode, ragged medium batches: %d boundaries over 64 utterances, within one frame %d, offenders %s" % (total, within, offenders))
+    assert total > 1500 and within == total and not offenders, offenders
+    # the live oracle reproduces the fixture on the shortest utterance
+    u = min(ids, key=lambda v: parity_ragged.spec(v)[0])
+    ns, ch = parity_ragged.spec(u)
+    rtok = tokenizer_ref.CharTokenizer()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(syn.synth_audio(u, ns))), audio.mel_filters(80))
+    tt = tokenizer_ref.encode_char(syn.synth_text(u, ch), rtok)
+    rw, _ = timing_ref.get_attentions(mel, torch.tensor([*rtok.sot_sequence, rtok.no_timestamps, *tt, rtok.eot]), whisper_ref.WhisperRef(sd, dims), ns // 320, 3, 1.0)
+    _rwords, rst, ren, _m, _s = timing_ref.force_align(rw, tt, rtok, "char", "topk", 10)
+    assert np.array_equal(np.asarray(rst), gold["st_%d" % u]) and np.array_equal(np.asarray(ren), gold["en_%d" % u]), u
+    del model
