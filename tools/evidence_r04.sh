@@ -5,17 +5,19 @@ set -o pipefail
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd "$ROOT" || exit 1
 mkdir -p gpurun_out
+if [ -z "$PMC_ONLY" ]; then
 timeout -k 10 600 python -m pytest tests -q -m gpu > gpurun_out/r04_final_gpu_tests.log 2>&1
 echo "gpu suite rc=$?"; tail -3 gpurun_out/r04_final_gpu_tests.log
 timeout -k 10 500 python bench.py --stages > gpurun_out/r04_bench_line.json 2> gpurun_out/r04_stage_ms.txt || { echo bench failed; tail -5 gpurun_out/r04_stage_ms.txt; exit 1; }
 cat gpurun_out/r04_bench_line.json | cut -c1-300
 timeout -k 10 300 python tools/parity_ragged.py --leg B > gpurun_out/ragged_B.log 2>&1 || { echo ragged B failed; tail -5 gpurun_out/ragged_B.log; exit 1; }
 tail -2 gpurun_out/ragged_B.log
+fi
 cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-f16-leg --aligned-utts 0 --no-overlap"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/r04_stats" -- python3 $B > "$ROOT/gpurun_out/r04_stats.log" 2>&1 || { echo stats failed; tail -5 "$ROOT/gpurun_out/r04_stats.log"; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$ROOT/gpurun_out/r04_pmc_fetch" -- python3 $B > "$ROOT/gpurun_out/r04_pmc_fetch.log" 2>&1 || { echo fetch pass failed; exit 1; }
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d "$ROOT/gpurun_out/r04_pmc_write" -- python3 $B > "$ROOT/gpurun_out/r04_pmc_write.log" 2>&1 || { echo write pass failed; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$ROOT/gpurun_out/r04_pmc_fetch" -- python3 $B > "$ROOT/gpurun_out/r04_pmc_fetch.log" 2>&1 || { echo fetch pass failed; exit 1; }
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$ROOT/gpurun_out/r04_pmc_write" -- python3 $B > "$ROOT/gpurun_out/r04_pmc_write.log" 2>&1 || { echo write pass failed; exit 1; }
 cd "$ROOT"
 python tools/pmc_bytes.py gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write head_stats layernorm_pair aggregate_kernel > gpurun_out/r04_hbm_kernels.txt 2>&1
 cat gpurun_out/r04_hbm_kernels.txt
