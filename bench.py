@@ -625,7 +625,7 @@ def main():
         if precision != "f16":
             for k_, v_ in list(sym.items()):
                 if k_ == "attention":
-                    sym[k_] = v_.replace("attn32_kernel<false>", "attn_split_kernel<false, false, 4>") + " [pair operands: three MFMA passes per product; the " \
+                    sym[k_] = v_.replace("attn32_kernel<false>", "attn_split32_kernel") + " [pair operands: three MFMA passes per product; the " \
                         "MFMA pipe executes 3x the algorithmic flops quoted]"
                 elif "gemm256p" in v_:
                     sym[k_] = v_.replace("gemm256p_f16_kernel<0,", "gemm256p_f16_kernel<4,").replace(", false>", ", false, true>") \

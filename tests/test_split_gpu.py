@@ -151,9 +151,16 @@ def _attn_ref64(q, k, v, H, causal):
     (1, 1, 5, 1500, 0, 145), (2, 6, 1500, 1500, 0, 0), (1, 2, 97, 33, 0, 0), (3, 1, 129, 64, 1, 0), (1, 5, 2, 65, 0, 64),
     (1, 2, 128, 64, 0, 0), (2, 2, 257, 129, 0, 0), (1, 3, 300, 1, 0, 0), (1, 2, 600, 130, 0, 0), (1, 1, 512, 64, 0, 0), (2, 1, 700, 128, 0, 0),
     (1, 2, 1030, 260, 0, 0)])
-def test_split_attention_is_fp32_accurate(eng, lib, wca, B, H, nq, nk, causal, cap_cols):
-    """attn_split_kernel (three MFMA passes per product on hi / lo pairs, fp32 online softmax on the exact logits) against a
-    float64 attention: output and captured logits at fp32 accuracy. A few large logits exercise the running-maximum update."""
+@pytest.mark.parametrize("variant", [0, 1])
+def test_split_attention_is_fp32_accurate(eng, lib, wca, monkeypatch, B, H, nq, nk, causal, cap_cols, variant):
+    """attn_split_kernel / attn_split32_kernel (three MFMA passes per product on hi / lo pairs, fp32 online softmax on the exact logits)
+    against a float64 attention: output and captured logits at fp32 accuracy. A few large logits exercise the running-maximum update.
+    variant 0: the launcher's choice (the 32x32x16 kernel for unmasked, capture-free calls of >= 64 query rows); 1: the 16x16x32 kernel
+    everywhere (WCA_ATTN_SPLIT_VARIANT=1)."""
+    if variant:
+        if causal or cap_cols or nq < 64:
+            pytest.skip("the 16x16x32 kernel is the launcher's choice here already")
+        monkeypatch.setenv("WCA_ATTN_SPLIT_VARIANT", str(variant))
     g = torch.Generator().manual_seed(nq * 13 + nk)
     d = H * 64
     q = torch.randn(B, nq, d, generator=g)

@@ -42,7 +42,7 @@ SITES_REFERENCE = {
     "out_proj": ("gemm256p_f16_kernel<2, false, 1, false, true>", lambda d: (d, d), True),
     "fc1": ("gemm256p_f16_kernel<4, true, 1, false, true>", lambda d: (4 * d, d), False),
     "fc2": ("gemm256p_f16_kernel<2, false, 4, false, true>", lambda d: (d, 4 * d), True),
-    "attention": ("attn_split_kernel<false, false, 4>", None, False),
+    "attention": ("attn_split32_kernel", None, False),
 }
 
 

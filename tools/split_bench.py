@@ -84,13 +84,17 @@ def main():
     q2, k2, v2 = pair(q), pair(k_), pair(v)
     qh, kh, vh = q.half(), k_.half(), v.half()
     o, o2 = torch.empty_like(qh), torch.empty_like(q2)
-    t16, t3 = [], []
-    for _ in range(reps):
+    t16, t3, t3o = [], [], []
+    for _ in range(reps):   # interleaved: f16, pair 32x32x16 (the launcher's choice), pair 16x16x32 (WCA_ATTN_SPLIT_VARIANT=1)
         t16.append(timeit(lambda: chk(lib.wca_test_attention(eng._h, vp(qh), vp(kh), vp(vh), vp(o), None, 0, 0, B, H, S, S, 0))))
+        os.environ.pop("WCA_ATTN_SPLIT_VARIANT", None)
         t3.append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
+        os.environ["WCA_ATTN_SPLIT_VARIANT"] = "1"
+        t3o.append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
+        os.environ.pop("WCA_ATTN_SPLIT_VARIANT", None)
     fl = 4.0 * B * H * S * S * 64
-    print("attn enc B=%d H=%d S=%d  f16 %.3f ms (%.0f TF)  split %.3f ms (%.0f TF alg)" % (B, H, S, min(t16), fl / min(t16) / 1e9, min(t3), fl / min(t3) / 1e9), flush=True)
-
+    print("attn enc B=%d H=%d S=%d  f16 %.3f ms (%.0f TF)  pair 32x32x16 %.3f ms (%.0f TF alg)  pair 16x16x32 %.3f ms (%.0f TF alg)"
+          % (B, H, S, min(t16), fl / min(t16) / 1e9, min(t3), fl / min(t3) / 1e9, min(t3o), fl / min(t3o) / 1e9), flush=True)
 
 if __name__ == "__main__":
     main()

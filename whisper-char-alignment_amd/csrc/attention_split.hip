@@ -433,6 +433,331 @@ __global__ __launch_bounds__(NW * 64, (2 * NW * 64) / 256) void attn_split_kerne
 
 
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// attn_split32_kernel (round 4): the encoder form (no mask, no capture) of the pair attention on v_mfma_f32_32x32x16_f16 -- attention.hip's
+// attn32 structure carrying pairs. Why the other MFMA shape: a 16x16x32 MFMA occupies the matrix pipe for 16 cycles and the SIMD's vector
+// issue for 8 of them, a 32x32x16 for 32 and 8 (MI355X_MICROARCH.md, issue-cost table) -- the same FLOPs block half as much vector issue,
+// and this loop is issue-bound (profiles/r04_attn_split_pmc.txt: pipe time and vector time add up). What else the structure brings:
+//   * S^T accumulators start at -m_running (a persistent C operand rewritten only when a maximum is raised): exp2 applies to the MFMA
+//     result, no per-score subtraction;
+//   * P^T reaches the P.V MFMAs with no lane movement (k order permuted, V^T fetched transposed in that order);
+//   * K / V rows through buffer descriptors (rows past nk read as zero), per-lane offsets fixed, the tile advances through the scalar
+//     offset: no vector instruction on DMA addresses; ring slots are compile-time (every LDS offset an immediate);
+//   * per score: exp2, half a packed conversion, one mixed-precision fma for the lo half, half a packed add for the row sum.
+// Measured at 64 x 16 x 1500 x 1500 (tools/split_bench.py, interleaved): 1.644-1.677 ms against 1.690-1.713 for the 16x16x32 kernel (-2...-3 %):
+// the issue budget was not the whole story. What the experiments of this kernel say (all removed again): with K / V never re-staged
+// (wrong results, timing only) 1.50 ms, so the DMA is 9 % of it; ONE workgroup per CU (one wave per SIMD) 1.95 ms, i.e. the second wave
+// of a SIMD hides only a sixth of the first one's time; and a SOFTWARE-PIPELINED form (S^T of tile kt + 1 issued between the exp2 / pair
+// split instructions of tile kt, K running one tile ahead of V in the same ring; 260 VGPRs = one wave per SIMD; verified against float64)
+// also took 1.95 ms -- vector instructions interleaved with MFMAs inside ONE wave do not overlap them (tools/micro/mfma_valu_coexec.hip:
+// 4 MFMA + 24 v_fma per iteration in one wave take 270 cycles against 128 of pipe), and two waves per SIMD need 2 x 256 registers.
+// Same arithmetic contract as attn_split_kernel (three passes per product, fp32 online softmax with the deferred maximum, P and O split
+// into pairs); the fp32 summation ORDER differs (k steps of 16 instead of 32, -m inside the accumulator), so results agree to fp32
+// noise, not bit for bit -- tests/test_split_gpu.py compares both with float64.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr float RESCALE_THR32 = 8.0f;
+
+__device__ __forceinline__ float max3f_(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+template <int V>
+struct IntC32 {
+  static constexpr int value = V;
+};
+#define WCA_S_PIN8(A, B, C, D, E, F, G, H) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H)::"memory")
+
+__global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
+  constexpr int NW = 4;  // waves per workgroup, 32 query rows each
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half_t* lds = reinterpret_cast<half_t*>(smem);  // [slot][K hi | K lo | V hi | V lo]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hh = lane >> 5;
+  constexpr int QB = NW * 32;
+  constexpr int TB = TILE * (int)sizeof(half_t);  // 8 KiB: one operand tile
+  constexpr int SLOT_BYTES = 4 * TB;              // 32 KiB
+  const int n_qt = (a.nq + QB - 1) / QB;
+  const int lid = xcd_remap(blockIdx.x, n_qt * a.H * a.B);
+  const int bh = lid / n_qt;
+  const int b = bh / a.H, h = bh - b * a.H;
+  const int q_wave = (lid - bh * n_qt) * QB + wave * 32;
+  const int qrow = q_wave + l31;
+
+  // Q fragments (B operand of S^T): lane holds Q[q = l31][dim = 16 ks + 8 hh + j]; the pair is multiplied by scale * log2(e) once and
+  // split again, so the scores leave the MFMAs in the log2 domain
+  const float c_log2 = a.scale * LOG2E;
+  half8 qh[4], ql[4];
+  {
+    const int qc = qrow < a.nq ? qrow : a.nq - 1;
+    const half_t* qp = a.Q + (long)b * a.q_bs + (long)qc * a.q_rs + h * 64 + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const half8 rh = *reinterpret_cast<const half8*>(qp + ks * 16);
+      const half8 rl = *reinterpret_cast<const half8*>(qp + a.q_lo + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const HalfPair pr = split_pair(((float)rh[j] + (float)rl[j]) * c_log2);
+        qh[ks][j] = pr.hi;
+        ql[ks][j] = pr.lo;
+      }
+    }
+  }
+  const int nkt = (a.nk + KT - 1) / KT;
+  const int kbytes = (int)(((long)(a.nk - 1) * a.k_rs + 64) * 2), vbytes = (int)(((long)(a.nk - 1) * a.v_rs + 64) * 2);
+  const half_t* Kb = a.K + (long)b * a.k_bs + h * 64;
+  const half_t* Vb = a.V + (long)b * a.v_bs + h * 64;
+  const __amdgpu_buffer_rsrc_t rkh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Kb), 0, kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rkl = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Kb + a.k_lo), 0, kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvh = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Vb), 0, vbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvl = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(Vb + a.v_lo), 0, vbytes, 0x00020000);
+  unsigned dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {  // 8 pieces of 8 key rows per tile and operand, two per wave
+    const int r = (wave * 2 + i) * 8 + (lane >> 3);
+    dk[i] = (unsigned)(r * a.k_rs * 2 + (((lane & 7) ^ ((r >> 1) & 7)) << 4));
+    dv[i] = (unsigned)(r * a.v_rs * 2 + (((lane & 7) ^ ((r & 2) << 1)) << 4));
+  }
+  const unsigned k_tile_bytes = (unsigned)(KT * a.k_rs * 2), v_tile_bytes = (unsigned)(KT * a.v_rs * 2);
+  auto stage = [&](int buf, int kt) {
+    half_t* Kh = lds + buf * (4 * TILE);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int rbase = (wave * 2 + i) * 8;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rkh, (WCA_LDS void*)(Kh + rbase * 64), 16, (int)dk[i], (int)(kt * k_tile_bytes), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rkl, (WCA_LDS void*)(Kh + TILE + rbase * 64), 16, (int)dk[i], (int)(kt * k_tile_bytes), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rvh, (WCA_LDS void*)(Kh + 2 * TILE + rbase * 64), 16, (int)dv[i], (int)(kt * v_tile_bytes), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rvl, (WCA_LDS void*)(Kh + 3 * TILE + rbase * 64), 16, (int)dv[i], (int)(kt * v_tile_bytes), 0, 0);
+    }
+  };
+
+  // per-lane LDS byte addresses in slot 0 / the hi tiles (slot, lo tile and fragment index are immediates), as in attn32_kernel
+  const int kswz = (l31 >> 1) & 7;
+  const unsigned lds_base = lds_off_s(lds);
+  unsigned ka[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) ka[ks] = lds_base + (unsigned)(l31 * 128 + 16 * ((hh ^ kswz) & 1) + 32 * (ks ^ (kswz >> 1)));
+  const int vq = (lane & 15) >> 2, vp = lane & 3, vg1 = (lane >> 4) & 1;
+  const int vkey0 = 4 * hh + vq;
+  const int vdim0 = 16 * vg1 + 4 * vp;
+  const int vsw = (vkey0 & 2) << 1;
+  unsigned va[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+    va[db] = lds_base + (unsigned)(2 * TB + vkey0 * 128 + (((4 * db + (vdim0 >> 3)) ^ vsw) << 4) + 2 * (vdim0 & 7));
+
+  f32x16 ot[2];
+#pragma unroll
+  for (int d = 0; d < 2; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_run = -INFINITY;  // running row maximum (log2 domain)
+  float l_run = 0.f;        // this lane's share of the row sum (its 32 keys per tile); the two lane halves are combined at the end
+  f32x16 cinit;             // -m_run in all 16 registers: the C operand of the first S^T MFMA of every key block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+
+  stage(0, 0);
+  auto tile = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int SB = SLOT * SLOT_BYTES;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (requested one tile ago) have landed
+    __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done with the other slot
+    asm volatile("" ::: "memory");
+    if (kt + 1 < nkt) stage(SLOT ^ 1, kt + 1);
+
+    // ---- S^T: st[kb][r] = s'(q = l31, key = 64 kt + 32 kb + (r&3) + 8 (r>>2) + 4 hh) - m_running; per k step the small terms first
+    f32x16 st[2];
+    {
+      half8 kl0[4], kh0[4], kl1[4], kh1[4];
+      kl0[0] = b128_read_asm<SB + TB>(ka[0]);
+      kl0[1] = b128_read_asm<SB + TB>(ka[1]);
+      kl0[2] = b128_read_asm<SB + TB>(ka[2]);
+      kl0[3] = b128_read_asm<SB + TB>(ka[3]);
+      kh0[0] = b128_read_asm<SB>(ka[0]);
+      kh0[1] = b128_read_asm<SB>(ka[1]);
+      kh0[2] = b128_read_asm<SB>(ka[2]);
+      kh0[3] = b128_read_asm<SB>(ka[3]);
+      kl1[0] = b128_read_asm<SB + TB + 32 * 128>(ka[0]);
+      kl1[1] = b128_read_asm<SB + TB + 32 * 128>(ka[1]);
+      kl1[2] = b128_read_asm<SB + TB + 32 * 128>(ka[2]);
+      kl1[3] = b128_read_asm<SB + TB + 32 * 128>(ka[3]);
+      kh1[0] = b128_read_asm<SB + 32 * 128>(ka[0]);
+      kh1[1] = b128_read_asm<SB + 32 * 128>(ka[1]);
+      kh1[2] = b128_read_asm<SB + 32 * 128>(ka[2]);
+      kh1[3] = b128_read_asm<SB + 32 * 128>(ka[3]);
+      WCA_S_LGKM_WAIT4(12, kl0[0], kl0[1], kl0[2], kl0[3]);
+      st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0[0], qh[0], cinit, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0[ks], qh[ks], st[0], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(8, kh0[0], kh0[1], kh0[2], kh0[3]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0[ks], ql[ks], st[0], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0[ks], qh[ks], st[0], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(4, kl1[0], kl1[1], kl1[2], kl1[3]);
+      st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1[0], qh[0], cinit, 0, 0, 0);
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1[ks], qh[ks], st[1], 0, 0, 0);
+      WCA_S_LGKM_WAIT4(0, kh1[0], kh1[1], kh1[2], kh1[3]);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], ql[ks], st[1], 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], qh[ks], st[1], 0, 0, 0);
+    }
+    // V^T fragments (hi and lo) of the first 32 output dims: requested now, they land under the softmax
+    half4 v0ha[4], v0hb[4], v0la[4], v0lb[4], v1ha[4], v1hb[4], v1la[4], v1lb[4];
+#define WCA_ISSUE_V32(P, DB)                                           \
+  do {                                                                 \
+    P##ha[0] = tr_read_asm<SB + 0 * 2048>(va[DB]);                     \
+    P##hb[0] = tr_read_asm<SB + 0 * 2048 + 1024>(va[DB]);              \
+    P##ha[1] = tr_read_asm<SB + 1 * 2048>(va[DB]);                     \
+    P##hb[1] = tr_read_asm<SB + 1 * 2048 + 1024>(va[DB]);              \
+    P##ha[2] = tr_read_asm<SB + 2 * 2048>(va[DB]);                     \
+    P##hb[2] = tr_read_asm<SB + 2 * 2048 + 1024>(va[DB]);              \
+    P##ha[3] = tr_read_asm<SB + 3 * 2048>(va[DB]);                     \
+    P##hb[3] = tr_read_asm<SB + 3 * 2048 + 1024>(va[DB]);              \
+    P##la[0] = tr_read_asm<SB + TB + 0 * 2048>(va[DB]);                \
+    P##lb[0] = tr_read_asm<SB + TB + 0 * 2048 + 1024>(va[DB]);         \
+    P##la[1] = tr_read_asm<SB + TB + 1 * 2048>(va[DB]);                \
+    P##lb[1] = tr_read_asm<SB + TB + 1 * 2048 + 1024>(va[DB]);         \
+    P##la[2] = tr_read_asm<SB + TB + 2 * 2048>(va[DB]);                \
+    P##lb[2] = tr_read_asm<SB + TB + 2 * 2048 + 1024>(va[DB]);         \
+    P##la[3] = tr_read_asm<SB + TB + 3 * 2048>(va[DB]);                \
+    P##lb[3] = tr_read_asm<SB + TB + 3 * 2048 + 1024>(va[DB]);         \
+  } while (0)
+    WCA_ISSUE_V32(v0, 0);
+    if (kt * KT + KT > a.nk) {  // keys past nk (last tile only): wave-uniform
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * KT + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          st[kb][r] = key >= a.nk ? -INFINITY : st[kb][r];
+        }
+    }
+    float mx;
+    {
+      float m0 = max3f_(st[0][0], st[0][1], st[0][2]), m1 = max3f_(st[0][3], st[0][4], st[0][5]);
+      float m2 = max3f_(st[0][6], st[0][7], st[0][8]), m3 = max3f_(st[0][9], st[0][10], st[0][11]);
+      m0 = max3f_(m0, st[0][12], st[0][13]);
+      m1 = max3f_(m1, st[0][14], st[0][15]);
+      m2 = max3f_(m2, st[1][0], st[1][1]);
+      m3 = max3f_(m3, st[1][2], st[1][3]);
+      m0 = max3f_(m0, st[1][4], st[1][5]);
+      m1 = max3f_(m1, st[1][6], st[1][7]);
+      m2 = max3f_(m2, st[1][8], st[1][9]);
+      m3 = max3f_(m3, st[1][10], st[1][11]);
+      m0 = max3f_(m0, st[1][12], st[1][13]);
+      m1 = max3f_(m1, st[1][14], st[1][15]);
+      mx = fmaxf(max3f_(m0, m1, m2), m3);
+      mx = xor32_maxf(mx);
+    }
+    // deferred maximum: raised when the tile maximum of (s' - m) exceeds the threshold, or anything finite arrives while m is still -inf
+    if (__any((mx > RESCALE_THR32) || (m_run == -INFINITY && mx != -INFINITY))) {
+      const float m_eff = (m_run == -INFINITY) ? 0.f : m_run;
+      const float m_new = fmaxf(m_run, mx + m_eff);
+      const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_eff;
+      const float alpha = (m_run == -INFINITY) ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] -= delta;
+      m_run = m_new;
+      const float c0 = (m_new != -INFINITY) ? -m_new : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = c0;
+    }
+    // p = exp2(s' - m) as a pair; P^T fragment of k step s4 (16 keys): registers 8 (s4 & 1) .. +7 of key block s4 >> 1
+    half8 ph[4], pl[4];
+    {
+      f32x2 psum = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        half2_ hq[4], lq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int r0 = 8 * (s4 & 1) + 2 * u;
+          const f32x2 p = f32x2{__builtin_amdgcn_exp2f(st[s4 >> 1][r0]), __builtin_amdgcn_exp2f(st[s4 >> 1][r0 + 1])};
+          psum += p;
+          hq[u] = __builtin_convertvector(p, half2_);
+          const unsigned hu = __builtin_bit_cast(unsigned, hq[u]);
+          unsigned lu;
+          asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lu) : "v"(p[0]), "v"(hu));
+          asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lu) : "v"(p[1]), "v"(hu));
+          lq[u] = __builtin_bit_cast(half2_, lu);
+        }
+        ph[s4] = half8{hq[0][0], hq[0][1], hq[1][0], hq[1][1], hq[2][0], hq[2][1], hq[3][0], hq[3][1]};
+        pl[s4] = half8{lq[0][0], lq[0][1], lq[1][0], lq[1][1], lq[2][0], lq[2][1], lq[3][0], lq[3][1]};
+      }
+      l_run += psum[0] + psum[1];
+    }
+    // ---- O^T += V^T P^T: A operand element j of lane half hh = V[key 16 s4 + 8 (j>>2) + 4 hh + (j&3)][d = 32 db + l31]
+    WCA_S_LGKM_WAIT8(0, v0ha[0], v0hb[0], v0ha[1], v0hb[1], v0ha[2], v0hb[2], v0ha[3], v0hb[3]);
+    WCA_S_PIN8(v0la[0], v0lb[0], v0la[1], v0lb[1], v0la[2], v0lb[2], v0la[3], v0lb[3]);
+    WCA_ISSUE_V32(v1, 1);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const half8 wh = __builtin_shufflevector(v0ha[s4], v0hb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+      const half8 wl = __builtin_shufflevector(v0la[s4], v0lb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[0], 0, 0, 0);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[0], 0, 0, 0);
+      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph[s4], ot[0], 0, 0, 0);
+    }
+    WCA_S_LGKM_WAIT8(0, v1ha[0], v1hb[0], v1ha[1], v1hb[1], v1ha[2], v1hb[2], v1ha[3], v1hb[3]);
+    WCA_S_PIN8(v1la[0], v1lb[0], v1la[1], v1lb[1], v1la[2], v1lb[2], v1la[3], v1lb[3]);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const half8 wh = __builtin_shufflevector(v1ha[s4], v1hb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+      const half8 wl = __builtin_shufflevector(v1la[s4], v1lb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[1], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[1], 0, 0, 0);
+      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph[s4], ot[1], 0, 0, 0);
+    }
+#undef WCA_ISSUE_V32
+  };
+  for (int kt = 0; kt < nkt; kt += 2) {
+    tile(IntC32<0>{}, kt);
+    if (kt + 1 < nkt) tile(IntC32<1>{}, kt + 1);
+  }
+
+  // ---- epilogue: ot[db][r] = O[q = l31][d = 32 db + (r&3) + 8 (r>>2) + 4 hh]; the two halves of a row are swapped pairwise so that
+  // each lane stores 16 contiguous bytes of the hi row and of the lo row
+  const float inv = 1.0f / xor32_sumf(l_run);
+  half_t* op = a.O + (long)b * a.o_bs + (long)qrow * a.o_rs + h * 64;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      unsigned wh[2][2], wl[2][2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          const Half2Pair pr = split_pair2(ot[db][4 * (2 * g2 + e) + 2 * k2] * inv, ot[db][4 * (2 * g2 + e) + 2 * k2 + 1] * inv);
+          wh[e][k2] = __builtin_bit_cast(unsigned, pr.hi);
+          wl[e][k2] = __builtin_bit_cast(unsigned, pr.lo);
+        }
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 oh, ol;
+      {
+        auto r0 = __builtin_amdgcn_permlane32_swap(wh[0][0], wh[1][0], false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(wh[0][1], wh[1][1], false, false);
+        oh = u32x4{r0[0], r1[0], r0[1], r1[1]};
+        auto s0 = __builtin_amdgcn_permlane32_swap(wl[0][0], wl[1][0], false, false);
+        auto s1 = __builtin_amdgcn_permlane32_swap(wl[0][1], wl[1][1], false, false);
+        ol = u32x4{s0[0], s1[0], s0[1], s1[1]};
+      }
+      if (qrow < a.nq) {
+        *reinterpret_cast<u32x4*>(op + 32 * db + 16 * g2 + 8 * hh) = oh;
+        *reinterpret_cast<u32x4*>(op + a.o_lo + 32 * db + 16 * g2 + 8 * hh) = ol;
+      }
+    }
+}
+
 }  // namespace
 
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
@@ -450,6 +775,16 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;                                                                                           \
     hipLaunchKernelGGL((attn_split_kernel<C, P, W>), dim3(((a.nq + (W) * 32 - 1) / ((W) * 32)) * a.H * a.B), dim3((W) * 64), shmem, s, a); \
   } while (0)
+  // the encoder form (no mask, no capture) on the 32x32x16 kernel; AttnArgs.variant 1 (tests / A-B: WCA_ATTN_SPLIT_VARIANT=1) keeps the 16x16x32 one
+  const char* ev = std::getenv("WCA_ATTN_SPLIT_VARIANT");
+  const int env_variant = ev ? atoi(ev) : 0;
+  const int variant = a.variant ? a.variant : env_variant;
+  if (!a.causal && !cap && a.nq >= 64 && variant != 1 && (a.o_rs % 8) == 0 && (a.o_lo % 8) == 0) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(attn_split32_kernel, dim3(((a.nq + 127) / 128) * a.H * a.B), dim3(256), shmem, s, a);
+    return hipGetLastError();
+  }
   if (a.causal) {
     if (cap) WCA_LAUNCH_AS(true, true, 4); else WCA_LAUNCH_AS(true, false, 4);
   } else {
