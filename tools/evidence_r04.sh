@@ -21,6 +21,8 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$ROOT/gpuru
 cd "$ROOT"
 python tools/pmc_bytes.py gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write head_stats layernorm_pair aggregate_kernel > gpurun_out/r04_hbm_kernels.txt 2>&1
 cat gpurun_out/r04_hbm_kernels.txt
+for site in attention fc1 fc2 qkv; do WCA_PRECISION=reference python tools/pmc_traffic.py gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_traffic_${site}_reference.json $site > /dev/null 2>&1 || echo "traffic $site failed"; done
+python -c "import json; [print(s, json.load(open('gpurun_out/r04_traffic_%s_reference.json' % s)).get('traffic_bytes_per_launch')) for s in ('attention','fc1','fc2','qkv')]"
 f=$(find gpurun_out/r04_stats -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r04_bench_kernel_stats_final.csv && head -12 "$f" | cut -c1-200
 # keep the merge-back small: drop the raw per-dispatch traces
 rm -rf gpurun_out/r04_stats gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write
