@@ -19,6 +19,7 @@
 #include <atomic>
 
 #include "gemm_epilogue.h"
+#include <cstdlib>
 #include "kernels.h"
 #include "wca_common.h"
 
@@ -921,7 +922,10 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const int nk = (splitw ? 2 : 1) * (a.K / BK);
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
       // (K <= 2048 since round 3: the K-doubled QKV / fc1 of the split mode measure -5 % / -3 % with the supertile order, same-box A/B)
-      if (a.supertile <= 0) a.supertile = ((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1;
+      if (a.supertile <= 0) {
+        const char* ev = std::getenv("WCA_GEMM_SUPERTILE");   // (tile-order experiments)
+        a.supertile = ev ? atoi(ev) : (((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1);
+      }
     }
   } else {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
