@@ -36,9 +36,9 @@ def spec(u):
     return n_samples, chars
 
 
-def oracle_word_times(leg, cfg, sd, dims, syn, audio_mod, ids, only_cached=False):
+def oracle_word_times(leg, cfg, sd, dims, syn, audio_mod, ids, only_cached=False, model="medium"):
     from oracle import timing_ref, whisper_ref, tokenizer_ref
-    key = "oracle_ragged_%s_medium_peaky008_ids%d-%d" % (leg, ids[0], ids[-1])
+    key = "oracle_ragged_%s_%s_peaky008_ids%d-%d" % (leg, model, ids[0], ids[-1])
     path = os.path.join(ROOT, "tools", "cache", key + ".npz")
     store = {}
     for p in (path, path + ".part.npz"):
@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--first-id", type=int, default=20000)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--modes", default="reference,f16")
+    ap.add_argument("--model", default="medium", help="dimension family (wca.dims_for): medium | large-v2 | large-v3 ...")
     ap.add_argument("--oracle-only", action="store_true")
     args = ap.parse_args()
     cfg = LEGS[args.leg]
@@ -91,10 +92,10 @@ def main():
     wca = importlib.import_module("whisper-char-alignment_amd")
     m = lambda n: importlib.import_module("whisper-char-alignment_amd." + n)  # noqa: E731
     syn, tok_mod, retok, timing, audio_mod = m("synthetic"), m("tokenizer"), m("retokenize"), m("timing"), m("audio")
-    dims = wca.dims_for("medium")
+    dims = wca.dims_for(args.model)
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
     ids = list(range(args.first_id, args.first_id + args.utts))
-    oracle, cache_path = oracle_word_times(args.leg, cfg, sd, dims, syn, audio_mod, ids, only_cached=not args.oracle_only and not os.environ.get("WCA_ORACLE_ON_GPU_BOX"))
+    oracle, cache_path = oracle_word_times(args.leg, cfg, sd, dims, syn, audio_mod, ids, only_cached=not args.oracle_only and not os.environ.get("WCA_ORACLE_ON_GPU_BOX"), model=args.model)
     if args.oracle_only:
         print("oracle word times:", cache_path)
         return
@@ -120,12 +121,12 @@ def main():
             toks[j, :len(r)] = r
         batches.append(dict(lo=lo, n=len(chunk), pcm=torch.from_numpy(pcm).to(device), tokens=torch.from_numpy(toks).to(device),
                             n_samples=[s for s, _ in sp], n_tok=[len(r) for r in rows], frames=[s // 320 for s, _ in sp], tts=tts))
-    lines, record = [], dict(leg=args.leg, settings=cfg, utterances=len(ids), first_id=args.first_id, ids="%d-%d" % (ids[0], ids[-1]),
+    lines, record = [], dict(leg=args.leg, model=args.model, settings=cfg, utterances=len(ids), first_id=args.first_id, ids="%d-%d" % (ids[0], ids[-1]),
                              seconds_range=[min(spec(u)[0] for u in ids) / 16000.0, max(spec(u)[0] for u in ids) / 16000.0],
                              chars_range=[min(spec(u)[1] for u in ids), max(spec(u)[1] for u in ids)], modes={})
-    head = ("ragged parity leg %s: %d utterances (ids %s), %.1f-%.1f s audio, %d-%d characters, whisper-medium dims, peaky seeded weights, char units, "
+    head = ("ragged parity leg %s: %d utterances (ids %s), %.1f-%.1f s audio, %d-%d characters, whisper-%s dims, peaky seeded weights, char units, "
             "aggr %s%s, medfilt %d; fused wca_align_batch at B = %d against the fp32 CPU oracle"
-            % (args.leg, len(ids), record["ids"], record["seconds_range"][0], record["seconds_range"][1], record["chars_range"][0], record["chars_range"][1],
+            % (args.leg, len(ids), record["ids"], record["seconds_range"][0], record["seconds_range"][1], record["chars_range"][0], record["chars_range"][1], args.model,
                cfg["aggr"], " topk %d" % cfg["topk"] if cfg["aggr"] == "topk" else "", cfg["medfilt"], args.batch))
     print(head, flush=True)
     lines.append(head)
@@ -153,7 +154,7 @@ def main():
         lines.append(line)
         record["modes"][mode] = dict(boundaries=total, within_one_frame=within, identical=ident, worst_s=worst, offenders=offenders)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    base = os.path.join(ROOT, "gpurun_out", "r04_parity_ragged_%s" % args.leg)
+    base = os.path.join(ROOT, "gpurun_out", "r04_parity_ragged_%s%s" % (args.leg, "" if args.model == "medium" else "_" + args.model))
     open(base + ".txt", "w").write("\n".join(lines) + "\n")
     json.dump(record, open(base + ".json", "w"), indent=1)
 
