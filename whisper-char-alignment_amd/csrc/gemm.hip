@@ -58,7 +58,16 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
       for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
     if (GELU) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = (OUT_MODE == 4) ? gelu_erf_exact(v[j]) : gelu_erf(v[j]);
+      for (int j = 0; j < 16; j += 2) {
+        if (OUT_MODE == 4) {   // pair output: the erf GELU to fp32 accuracy, two elements per packed instruction
+          const f32x2 g = gelu_erfc2(f32x2{v[j], v[j + 1]});
+          v[j] = g[0];
+          v[j + 1] = g[1];
+        } else {
+          v[j] = gelu_erf(v[j]);
+          v[j + 1] = gelu_erf(v[j + 1]);
+        }
+      }
     }
     if (a.pos != nullptr) {
       const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nb;

@@ -85,7 +85,16 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
     if (m >= a.M) continue;
     if (GELU) {
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = (OUT_MODE == 4) ? gelu_erf_exact(v[j]) : gelu_erf(v[j]);
+      for (int j = 0; j < 16; j += 2) {
+        if (OUT_MODE == 4) {   // pair output: the erf GELU to fp32 accuracy, two elements per packed instruction
+          const f32x2 g = gelu_erfc2(f32x2{v[j], v[j + 1]});
+          v[j] = g[0];
+          v[j + 1] = g[1];
+        } else {
+          v[j] = gelu_erf(v[j]);
+          v[j + 1] = gelu_erf(v[j + 1]);
+        }
+      }
     }
     if (a.pos != nullptr) {
       const float* pp = a.pos + (long)(m % a.pos_period) * a.N + nbase;

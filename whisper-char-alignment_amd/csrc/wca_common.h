@@ -82,6 +82,40 @@ __device__ __forceinline__ float gelu_erf(float x) {
 // to ~22 bits, so its 3e-7 absolute error would show.
 __device__ __forceinline__ float gelu_erf_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// The same erf GELU on TWO elements with packed fp32 instructions, for the pair-output epilogues (round 4): the device library's erff is
+// ~45 vector instructions per element once both of its branches are if-converted, and the GELU epilogue was 15-17 % of the pair fc1 launch.
+//   GELU(x) = max(x, 0) - |x| h,   h = erfc(|x| / sqrt 2) / 2 = t exp(-z^2 + P(t)) / 2,   z = |x| / sqrt 2,  t = 1 / (1 + z / 2)
+// with P the degree-9 Chebyshev fit of Numerical Recipes' erfcc (fractional error of erfc < 1.2e-7 EVERYWHERE, so the negative tail keeps
+// its relative accuracy -- the reference's own fp32 expression x 0.5 (1 + erf(x / sqrt 2)) loses it to cancellation). log2(e) and the
+// factor 1/2 are folded into the coefficients (exp2 of the scaled argument - 1). ~13.5 vector issue slots per element: |x|, 1 + z/2, v_rcp,
+// nine packed fmas, x^2, the exponent, v_exp, t e, max(x, 0), |x| h, the difference. Against float64 over [-12, 12] in emulated fp32: absolute
+// error <= 1.1e-7 on |x| < 1, <= 2.1e-7 on 1 <= |x| < 3 (the fp32 rounding of the result itself: the reference formula measures 0.8e-7 / 2.5e-7),
+// relative error <= 4.7e-7 on [-1, 1], <= 1.4e-6 down to -3.
+__device__ __forceinline__ f32x2 gelu_erfc2(f32x2 x) {
+  constexpr float L2E = 1.4426950408889634f;
+  const f32x2 ax = f32x2{__builtin_fabsf(x[0]), __builtin_fabsf(x[1])};
+  const f32x2 d = __builtin_elementwise_fma(ax, f32x2{0.35355339059327373f, 0.35355339059327373f}, f32x2{1.0f, 1.0f});   // 1 + |x| / (2 sqrt 2)
+  const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 p = f32x2{0.17087277f * L2E, 0.17087277f * L2E};
+#define WCA_GH(C) p = __builtin_elementwise_fma(p, t, f32x2{(C) * L2E, (C) * L2E})
+  WCA_GH(-0.82215223f);
+  WCA_GH(1.48851587f);
+  WCA_GH(-1.13520398f);
+  WCA_GH(0.27886807f);
+  WCA_GH(-0.18628806f);
+  WCA_GH(0.09678418f);
+  WCA_GH(0.37409196f);
+  WCA_GH(1.00002368f);
+#undef WCA_GH
+  p = __builtin_elementwise_fma(p, t, f32x2{-1.26551223f * L2E - 1.0f, -1.26551223f * L2E - 1.0f});   // ... and the factor 1/2
+  const f32x2 w = x * x;
+  const f32x2 arg = __builtin_elementwise_fma(w, f32x2{-0.5f * L2E, -0.5f * L2E}, p);                     // log2(e) (P(t) - z^2) - 1
+  const f32x2 e = f32x2{__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+  const f32x2 h = t * e;
+  const f32x2 pos = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+  return pos - ax * h;
+}
+
 // x -> (hi, lo) with hi = f16(x), lo = f16(x - hi): x = hi + lo up to 2^-22 |x| (lo is exact in f32; it rounds to f16 with
 // 11 more bits, or to the f16 subnormal grid, 6e-8 absolute, for |x| below ~0.1). The value is PINNED in a register first:
 // with -ffp-contract=fast (the HIP default) hipcc otherwise folds the multiply that produced x into ONE of the two conversions
