@@ -60,6 +60,10 @@ def _compare(frames, sizes, label):
             worst = max(worst, int(d.max()))
             n_diff_frames += int((d > 0).sum())
             n_diff_utts += int(d.max() > 0)
+            if d.max() > 0:   # which frames, for the log
+                w = np.nonzero(d)[0]
+                _log("    %s: utterance %d at batch size %d: positions %s: batch-size-%d values %s, here %s"
+                     % (label.split(",")[0], i, B, w[:8].tolist(), sizes[0], base[i][w[:8]].tolist(), frames[B][i][w[:8]].tolist()))
     _log("%s: batch sizes %s, %d utterances: %d of %d jump frames differ from batch size %d (%d utterance x size pairs), largest difference %d frame(s)"
          % (label, sizes, len(base), n_diff_frames, total, sizes[0], n_diff_utts, worst))
     return worst, n_diff_frames

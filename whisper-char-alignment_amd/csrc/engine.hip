@@ -78,6 +78,14 @@ struct GrowBuf {
     hipError_t e = hipMalloc(&p, need);
     if (e != hipSuccess) return e;
     bytes = need;
+    // debugging aid: WCA_POISON_ALLOC=1 fills every grow-only buffer with 0xFF bytes (NaN as f32 / f16, -1 as an index) when it is
+    // allocated, so that a read of a never-written element shows as a wrong result on every run instead of depending on what the
+    // recycled memory held
+    static const bool poison = std::getenv("WCA_POISON_ALLOC") != nullptr;
+    if (poison) {
+      e = hipMemset(p, 0xFF, need);
+      if (e != hipSuccess) return e;
+    }
     return hipSuccess;
   }
   void release() {
