@@ -181,7 +181,7 @@ int wca_probe_strict_tp(wca_engine* e, int n_heads, const int32_t* word_end_row_
  * pcm_dev [batch][pcm_stride] f32 (NULL: re-use the encoder state of the preceding wca_greedy_decode of this
  * batch); tokens_dev [batch][n_tok_max] int64; n_tok_host, n_samples_host, max_frames_host [batch].
  * jump_frame_host [batch][n_tok_max]: for utterance b, entries [0, n_tok[b] - sot_len - 1) are the frame
- * index at which the DTW path enters that text row (jump_times * 50, timing.py:110-111).
+ * index at which the DTW path enters that text row (jump_times * 50, timing.py:110-111); the remaining entries of a row are 0.
  * sel_idx_host [batch][topk] may be NULL. */
 int wca_align_batch(wca_engine* e, const float* pcm_dev, int64_t pcm_stride, const int32_t* n_samples_host,
                     const int64_t* tokens_dev, int n_tok_max, const int32_t* n_tok_host,

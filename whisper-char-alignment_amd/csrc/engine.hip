@@ -1296,6 +1296,9 @@ int run_select_aggregate_dtw(wca_engine* e, const float* weights, int B, int LH,
     HIPCHK(e->path.ensure(sizeof(int) * (size_t)B * 2 * cap));
     HIPCHK(e->pathlen.ensure(sizeof(int) * (size_t)B));
     HIPCHK(e->jump.ensure(sizeof(int) * (size_t)B * n_max));
+    // the DTW writes n_tok[b] - sot_len - 1 entries per utterance; the rest of a row is defined as 0 (the buffer is recycled memory, and a
+    // caller that compares or stores whole rows must not see what an earlier allocation left there)
+    HIPCHK(hipMemsetAsync(e->jump.p, 0, sizeof(int) * (size_t)B * n_max, s));
     DtwArgs dg{};
     dg.matrix = (const float*)e->matrix.p;
     dg.m_bs = (long)n_max * Fmax;
