@@ -239,8 +239,6 @@ __global__ __launch_bounds__(256) void head_stats_kernel(HeadStatsArgs a) {
 //     That IS v_div_scale / v_div_fmas / v_div_fixup's result whenever no operand scaling triggers (sum in [1, 1536]: numerator >= 2^-100
 //     or 0); a row holding a smaller non-zero numerator (x < -68 on a valid column) takes the plain `/` instead;
 //   * wave reductions with the DPP operand folded into the add / max (same summation tree as wave_sum).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ float vmin_raw(float a, float b) {
   float r;
   asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));

@@ -77,13 +77,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return fmaxf(x, 0.f) - fabsf(h);
 }
 
-// Reference-precision ("split") mode: torch's erf GELU, x * 0.5 * (1 + erf(x / sqrt 2)), with the device library's erff
-// (<= 2 ulp). The polynomial above is exact to the f16 store that follows it in the default mode; here the value is kept
-// to ~22 bits, so its 3e-7 absolute error would show.
-__device__ __forceinline__ float gelu_erf_exact(float x) { return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// The same erf GELU on TWO elements with packed fp32 instructions, for the pair-output epilogues (round 4): the device library's erff is
-// ~45 vector instructions per element once both of its branches are if-converted, and the GELU epilogue was 15-17 % of the pair fc1 launch.
+// Reference-precision ("split") mode: torch's erf GELU, x * 0.5 * (1 + erf(x / sqrt 2)), to fp32 accuracy -- the polynomial above is exact
+// to the f16 store that follows it in the default mode; in the pair-output epilogues the value is kept to ~22 bits, so its 3e-7 absolute
+// error would show. Until round 4 this was the device library's erff (<= 2 ulp, but ~45 vector instructions per element once both of its
+// branches are if-converted: the GELU epilogue was 15-17 % of the pair fc1 launch); now, on TWO elements with packed fp32 instructions:
 //   GELU(x) = max(x, 0) - |x| h,   h = erfc(|x| / sqrt 2) / 2 = t exp(-z^2 + P(t)) / 2,   z = |x| / sqrt 2,  t = 1 / (1 + z / 2)
 // with P the degree-9 Chebyshev fit of Numerical Recipes' erfcc (fractional error of erfc < 1.2e-7 EVERYWHERE, so the negative tail keeps
 // its relative accuracy -- the reference's own fp32 expression x 0.5 (1 + erf(x / sqrt 2)) loses it to cancellation). log2(e) and the
