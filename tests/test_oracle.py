@@ -434,3 +434,39 @@ def test_oracle_word_time_fixture_is_reproduced_by_the_live_oracle():
     for s_, (l, h), _n in all_scores:
         live[l * 16 + h] = s_
     assert np.max(np.abs(live - gold["sc_%d" % u]) / np.abs(live)) < 1e-5
+
+
+def test_ragged_oracle_fixture_structure_and_one_live_utterance():
+    """tests/golden/oracle_word_times_ragged_A.npz (tools/parity_ragged.py leg A: 128 ragged utterances at whisper-medium dimensions, what
+    tests/test_e2e_gpu.py::test_contract_mode_parity_ragged_lengths compares the GPU path with): one (start, end) per word of the
+    utterance's text, monotone, inside the utterance's own duration; and the LIVE oracle reproduces the shortest utterance exactly."""
+    import importlib
+    import sys
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_ragged
+    wca = importlib.import_module("whisper-char-alignment_amd")
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_word_times_ragged_A.npz"))
+    ids = list(range(20000, 20128))
+    assert len(gold.files) == 2 * len(ids)
+    lengths = set()
+    for u in ids:
+        ns, ch = parity_ragged.spec(u)
+        st, en = gold["st_%d" % u], gold["en_%d" % u]
+        assert len(st) == len(en) == len(syn.synth_text(u, ch).split())
+        assert np.all(np.diff(en) >= 0) and np.all(st[1:] == en[:-1]) and 0 <= st[0] and en[-1] <= ns / 16000.0 + 0.02
+        lengths.add((ns // 320, ch))
+    assert len(lengths) > 100 and min(f for f, _ in lengths) < 150 and max(f for f, _ in lengths) > 1400   # ragged indeed
+    u = min(ids, key=lambda v: parity_ragged.spec(v)[0])
+    ns, ch = parity_ragged.spec(u)
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    tok = tokenizer_ref.CharTokenizer()
+    mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(syn.synth_audio(u, ns))), audio.mel_filters(80))
+    tt = tokenizer_ref.encode_char(syn.synth_text(u, ch), tok)
+    w, _ = timing_ref.get_attentions(mel, torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]), whisper_ref.WhisperRef(sd, dims), ns // 320, 3, 1.0)
+    _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", 10)
+    assert np.array_equal(np.asarray(st), gold["st_%d" % u]) and np.array_equal(np.asarray(en), gold["en_%d" % u])
+
