@@ -299,9 +299,16 @@ int wca_test_gemm_rows(wca_engine* e, const void* a_f16_dev, const float* x_f32_
                        const void* w_f16_dev, const float* bias_dev, void* c_dev, int M, int N, int K, int gelu, int out_mode, int splitk,
                        int groups, void* kv_k_f16_dev, void* kv_v_f16_dev, int T_max, int kv_t);
 /* diagnostic build of the pipelined 256x256 GEMM that records s_memtime stamps per K tile into dbg_dev
- * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product */
+ * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product.
+ * out_mode: bits 0-7 as wca_test_gemm (0 / 2 / 4), bit 8 GELU, bit 9 pair operands (a = [M][hi(K) | lo(K)], plain w: the SPLITW form),
+ * bits 12-15 / 16-19: when non-zero, tile coordinates are taken modulo these (m, n) -- an L2-resident operand footprint, outputs
+ * collide; with the wrap set dbg_dev may be NULL (no stamps: plain timing of the wrapped launch) */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
                           int out_mode, unsigned long long* dbg_dev);
+/* diagnostic, process-wide (the product never calls it; 0 = the contract's three passes per product): leave single MFMA passes out of the
+ * encoder's pair attention -- bit 0 K_lo Q_hi, bit 1 K_hi Q_lo, bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 12, 15 exist.
+ * tools/precision_ablation.py --attn-drop: the product-level ablation of timing.py:58's fp32 attention. */
+int wca_test_set_attn_split_drop(int mask);
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL.
  * causal: bit 0 = causal mask; bits 8-9 = kernel variant (0 auto, 1 the 16x16x32-MFMA kernel, 2 the 32x32x16-MFMA
  * kernel that serves the encoder's un-masked self-attention = what auto picks, 3 the same with the row sums on the vector

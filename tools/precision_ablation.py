@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--medfilt_width", type=int, default=3)
     ap.add_argument("--rows", default="", help="comma-separated row names (default: every row of the table); 'sites:a+b@first' adds a row")
+    ap.add_argument("--attn-drop", default="", help="comma-separated pass masks of the encoder's pair attention (wca_test_set_attn_split_drop: 1 K_lo Q_hi, 2 K_hi Q_lo, "
+                    "4 V_lo P_hi, 8 V_hi P_lo; 0, 1, 2, 3, 4, 8, 12, 15 exist): every mask becomes a row in the all-sites mode (VERDICT r4 item 2)")
     ap.add_argument("--oracle-only", action="store_true", help="compute / complete the oracle cache and stop (CPU only: runs without a GPU)")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "r04_precision_ablation.txt"))
     args = ap.parse_args()
@@ -150,12 +152,20 @@ def main():
                 sel += [r for r in ROWS if r[0] == w]
         rows = sel
 
+    drop_names = {0: "all six passes (contract)", 1: "without K_lo Q_hi", 2: "without K_hi Q_lo", 3: "S from K_hi Q_hi alone", 4: "without V_lo P_hi",
+                  8: "without V_hi P_lo", 12: "O from V_hi P_hi alone", 15: "one pass per product (pair operands elsewhere)"}
+    if args.attn_drop:
+        rows = [("attention passes: %s [mask %d]" % (drop_names.get(int(x), "?"), int(x)), "all", -1 - int(x)) for x in args.attn_drop.split(",")]
+
     lines = []
     hdr = "%-46s %9s %9s | %7s %7s %7s | %5s %5s | %s" % ("sites (encoder bits from block)", "utt/s", "ms/step", "bounds", "within", "ident", "utts", "clean", "offenders (utt:boundaries off, same heads?, oracle k/k+1 gap)")
     lines.append(hdr)
     print(hdr, flush=True)
     records = []
     for name, sites, first in rows:
+        if first < 0:   # an attention-pass row: all sites on pairs, the mask on the encoder's pair attention
+            wca._lib.check(model._lib.wca_test_set_attn_split_drop(-1 - first))
+            first = 0
         model.set_precision_sites(sites, first)
         # ---- parity
         total = within = ident = clean = 0
@@ -210,6 +220,8 @@ def main():
         print(line, flush=True)
         records.append(dict(row=name, sites=sites, enc_first_layer=first, utt_per_s=rate, ms_per_step=1e3 * el / args.steps, boundaries=total, within_one_frame=within,
                             identical=ident, utterances=len(ids), utterances_clean=clean, offenders=offenders))
+    if args.attn_drop:
+        wca._lib.check(model._lib.wca_test_set_attn_split_drop(0))
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as f:
         f.write("# tools/precision_ablation.py --utts %d --steps %d  (whisper-%s dims, peaky seeded weights, %.0f s audio, %d chars, topk %d, medfilt %d, fused B = %d;\n"

@@ -78,6 +78,7 @@ SIGNATURES = {
     "wca_test_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "wca_test_set_attn_split_drop": (_i, [_i]),
     "wca_test_gemm_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),

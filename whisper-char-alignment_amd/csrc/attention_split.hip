@@ -14,6 +14,7 @@
 // with the slot that tile kt + 1 is then requested into). Scores transposed (S^T = K Q^T) so that a query row is a lane column;
 // textbook online softmax in fp32 on the RAW scores (no deferred maximum, no pre-scaled Q: nothing is rounded to f16 before
 // the exponential); P is split like every other operand.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -464,6 +465,9 @@ struct IntC32 {
 };
 #define WCA_S_PIN8(A, B, C, D, E, F, G, H) asm volatile("" : "+v"(A), "+v"(B), "+v"(C), "+v"(D), "+v"(E), "+v"(F), "+v"(G), "+v"(H)::"memory")
 
+// DROP (diagnostic, wca_test_set_attn_split_drop; the product runs DROP = 0): bit 0 leaves out K_lo Q_hi, bit 1 K_hi Q_lo, bit 2 V_lo P_hi,
+// bit 3 V_hi P_lo -- the product-level ablation of the three-pass contract (tools/precision_ablation.py --attn-drop)
+template <int DROP>
 __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
   constexpr int NW = 4;  // waves per workgroup, 32 query rows each
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
       kh1[1] = b128_read_asm<SB + 32 * 128>(ka[1]);
       kh1[2] = b128_read_asm<SB + 32 * 128>(ka[2]);
       kh1[3] = b128_read_asm<SB + 32 * 128>(ka[3]);
+      if constexpr (DROP == 0) {
       WCA_S_LGKM_WAIT4(12, kl0[0], kl0[1], kl0[2], kl0[3]);
       st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0[0], qh[0], cinit, 0, 0, 0);
 #pragma unroll
@@ -602,6 +607,28 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
       for (int ks = 0; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], ql[ks], st[1], 0, 0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], qh[ks], st[1], 0, 0, 0);
+      } else {   // ablation forms: the same order with the dropped passes left out (the large term last)
+        WCA_S_LGKM_WAIT4(0, kh1[0], kh1[1], kh1[2], kh1[3]);
+        WCA_S_PIN8(kl0[0], kl0[1], kl0[2], kl0[3], kh0[0], kh0[1], kh0[2], kh0[3]);
+        WCA_S_PIN8(kl1[0], kl1[1], kl1[2], kl1[3], kh1[0], kh1[1], kh1[2], kh1[3]);
+        st[0] = cinit;
+        st[1] = cinit;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (!(DROP & 1)) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0[ks], qh[ks], st[0], 0, 0, 0);
+          if (!(DROP & 1)) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1[ks], qh[ks], st[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          if (!(DROP & 2)) st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0[ks], ql[ks], st[0], 0, 0, 0);
+          if (!(DROP & 2)) st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], ql[ks], st[1], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          st[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0[ks], qh[ks], st[0], 0, 0, 0);
+          st[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1[ks], qh[ks], st[1], 0, 0, 0);
+        }
+      }
     }
     // V^T fragments (hi and lo) of the first 32 output dims: requested now, they land under the softmax
     half4 v0ha[4], v0hb[4], v0la[4], v0lb[4], v1ha[4], v1hb[4], v1la[4], v1lb[4];
@@ -703,8 +730,8 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
     for (int s4 = 0; s4 < 4; ++s4) {
       const half8 wh = __builtin_shufflevector(v0ha[s4], v0hb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
       const half8 wl = __builtin_shufflevector(v0la[s4], v0lb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
-      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[0], 0, 0, 0);
-      ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[0], 0, 0, 0);
+      if (!(DROP & 4)) ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[0], 0, 0, 0);
+      if (!(DROP & 8)) ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[0], 0, 0, 0);
       ot[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph[s4], ot[0], 0, 0, 0);
     }
     WCA_S_LGKM_WAIT8(0, v1ha[0], v1hb[0], v1ha[1], v1hb[1], v1ha[2], v1hb[2], v1ha[3], v1hb[3]);
@@ -713,8 +740,8 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
     for (int s4 = 0; s4 < 4; ++s4) {
       const half8 wh = __builtin_shufflevector(v1ha[s4], v1hb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
       const half8 wl = __builtin_shufflevector(v1la[s4], v1lb[s4], 0, 1, 2, 3, 4, 5, 6, 7);
-      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[1], 0, 0, 0);
-      ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[1], 0, 0, 0);
+      if (!(DROP & 4)) ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, ph[s4], ot[1], 0, 0, 0);
+      if (!(DROP & 8)) ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, pl[s4], ot[1], 0, 0, 0);
       ot[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, ph[s4], ot[1], 0, 0, 0);
     }
 #undef WCA_ISSUE_V32
@@ -758,7 +785,11 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
     }
 }
 
+std::atomic<int> g_attn_split_drop{0};
+
 }  // namespace
+
+void set_attention_split_drop(int mask) { g_attn_split_drop.store(mask & 15, std::memory_order_relaxed); }
 
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
   if (a.nq <= 0 || a.B <= 0) return hipSuccess;
@@ -780,9 +811,24 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
   const int env_variant = ev ? atoi(ev) : 0;
   const int variant = a.variant ? a.variant : env_variant;
   if (!a.causal && !cap && a.nq >= 64 && variant != 1 && (a.o_rs % 8) == 0 && (a.o_lo % 8) == 0) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(attn_split32_kernel, dim3(((a.nq + 127) / 128) * a.H * a.B), dim3(256), shmem, s, a);
+#define WCA_LAUNCH_A32(D)                                                                                                             \
+  do {                                                                                                                                \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_split32_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem); \
+    if (e != hipSuccess) return e;                                                                                                    \
+    hipLaunchKernelGGL(attn_split32_kernel<D>, dim3(((a.nq + 127) / 128) * a.H * a.B), dim3(256), shmem, s, a);                       \
+  } while (0)
+    switch (g_attn_split_drop.load(std::memory_order_relaxed)) {   // 0 in the product; the other forms are the ablation's (wca_test_set_attn_split_drop)
+      case 0: WCA_LAUNCH_A32(0); break;
+      case 1: WCA_LAUNCH_A32(1); break;
+      case 2: WCA_LAUNCH_A32(2); break;
+      case 3: WCA_LAUNCH_A32(3); break;
+      case 4: WCA_LAUNCH_A32(4); break;
+      case 8: WCA_LAUNCH_A32(8); break;
+      case 12: WCA_LAUNCH_A32(12); break;
+      case 15: WCA_LAUNCH_A32(15); break;
+      default: return hipErrorInvalidValue;
+    }
+#undef WCA_LAUNCH_A32
     return hipGetLastError();
   }
   if (a.causal) {

@@ -2819,11 +2819,14 @@ int wca_test_gemm_rows(wca_engine* e, const void* a_f16, const float* x_f32, con
 }
 
 int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, int M, int N, int K, int out_mode, unsigned long long* dbg_dev) {
-  if (!e || !dbg_dev) return fail(WCA_ERR_INVALID, "null argument");
+  const int wrap_m = (out_mode >> 12) & 0xf, wrap_n = (out_mode >> 16) & 0xf;
+  if (!e || (!dbg_dev && wrap_m == 0)) return fail(WCA_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(e->device));
+  const bool pairs = (out_mode >> 9) & 1;
   GemmArgs g{};
   g.A = (const half_t*)a;
-  g.lda = K;
+  g.lda = pairs ? 2 * K : K;
+  g.a_lo = pairs ? K : 0;
   g.W = (const half_t*)w;
   g.ldw = K;
   g.C = c;
@@ -2832,14 +2835,28 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, 
   g.N = N;
   g.K = K;
   g.out_mode = out_mode & 0xff;
-  g.force_tile = 257;
+  g.gelu = (out_mode >> 8) & 1;
+  if (g.out_mode == 4) {
+    g.ldc = 2 * N;
+    g.c_lo = N;
+  }
+  g.site = 1;
+  g.force_tile = pairs ? 0 : 257;
   g.dbg = dbg_dev;
+  g.dbg_wrap_m = wrap_m;
+  g.dbg_wrap_n = wrap_n;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }
 
 int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, const void* v, void* o, int B, int H, int nq, int nk,
                                unsigned long long* dbg_dev);
+
+int wca_test_set_attn_split_drop(int mask) {
+  if (mask != 0 && mask != 1 && mask != 2 && mask != 3 && mask != 4 && mask != 8 && mask != 12 && mask != 15) return fail(WCA_ERR_INVALID, "attention pass mask %d is not instantiated", mask);
+  set_attention_split_drop(mask);
+  return WCA_OK;
+}
 
 static int test_attention_impl(wca_engine* e, const void* q, const void* k, const void* v, void* o, float* cap_dev, int cap_ld, int cap_cols,
                                int B, int H, int nq, int nk, int causal, unsigned long long* dbg) {

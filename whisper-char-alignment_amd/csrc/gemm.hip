@@ -434,7 +434,8 @@ struct GemmIntC {
   static constexpr int value = V;
 };
 
-template <int OUT_MODE, bool GELU, int SITE, bool STAMP = false, bool SPLITW = false>
+// STAMP: 0 product; 1 s_memtime stamps (+ the tile wrap below); 2 the tile wrap alone (timing of an L2-resident operand footprint)
+template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, bool SPLITW = false>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
@@ -546,6 +547,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     const int rows = (ntm - st * SM) < SM ? (ntm - st * SM) : SM;  // the last supertile may be short
     tn = r / rows;
     tm = st * SM + (r - tn * rows);
+    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15) {   // (15: the diagnostic build without the wrap)   // diagnostic builds: every workgroup walks the same few panels (operands L2-resident; outputs collide)
+      tm %= a.dbg_wrap_m;
+      tn %= a.dbg_wrap_n;
+    }
   };
   // OUT_MODE 3 (LayerNorm in the epilogue): the N/256 workgroups that hold one 256-row panel wait for each other in the
   // epilogue, so a panel's tiles must be worked on AT THE SAME TIME: round r of the 32 workgroups that share an XCD label
@@ -599,7 +604,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 
 #define WCA_STAMP(IDX)                                                                      \
   do {                                                                                     \
-    if (STAMP) {                                                                           \
+    if (STAMP == 1) {                                                                      \
       unsigned long long t_;                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                   \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");          \
@@ -705,7 +710,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     //  base addresses stay live; the runtime parity costs two scalar branches per step)
     for (int kt = 0; kt < nk; ++kt) kstep(GemmIntC<-1>{}, kt);
 
-    if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
+    if (STAMP == 1 && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
       a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 0] = __builtin_readcyclecounter();
     {
       // opaque copies: keeps the epilogue's per-lane address arithmetic from being hoisted out of the tile loop
@@ -723,7 +728,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       else
         epilogue_wide<OUT_MODE, GELU, KernArgs>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64);
     }
-    if (STAMP && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
+    if (STAMP == 1 && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
       a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 1] = __builtin_readcyclecounter();
     if (!has_next) break;
     // next tile's bias -> the other buffer: its last readers (the epilogue two tiles back) are behind at least one
@@ -894,7 +899,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   // tile choice: the 256^2 kernel runs one workgroup per CU, so it needs about a full wave of 256 workgroups
   const long tiles256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
   const bool splitw = a.a_lo > 0;
-  if (splitw && (a.force_tile == 64 || a.force_tile == 128 || a.force_tile == 256 || a.a_rows_per_batch != 0 || a.dbg != nullptr ||
+  if (splitw && (a.force_tile == 64 || a.force_tile == 128 || a.force_tile == 256 || a.a_rows_per_batch != 0 ||
                  !gemm_splitw_supported(a.M, a.N, a.K, a.lda, a.out_mode) || (a.a_lo & 7) != 0))
     return hipErrorInvalidValue;
   const size_t a_need = ((size_t)(a.M - 1) * a.lda + (splitw ? (size_t)a.a_lo : 0) + a.K) * sizeof(half_t), w_need = ((size_t)(a.N - 1) * a.ldw + a.K) * sizeof(half_t);
@@ -967,28 +972,27 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     }                                                                                             \
     hipLaunchKernelGGL((KERN<OM, G, S>), grid, block, shmem, s, a);                               \
   } while (0)
-#define WCA_LAUNCH_K4(KERN, OM, G, S, ST)                                                         \
+#define WCA_LAUNCH_K4(KERN, OM, G, S, ST, SW)                                                     \
   do {                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, ST>),         \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, ST, SW>),     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
     if (e != hipSuccess) return e;                                                                \
-    hipLaunchKernelGGL((KERN<OM, G, S, ST>), grid, block, shmem, s, a);                           \
+    hipLaunchKernelGGL((KERN<OM, G, S, ST, SW>), grid, block, shmem, s, a);                       \
   } while (0)
 #define WCA_LAUNCH_K5(KERN, OM, G, S)                                                              \
   do {                                                                                              \
     static std::atomic<unsigned> attr_mask5{0};                                                     \
     if (!(attr_mask5.load(std::memory_order_acquire) & (1u << (dev & 31)))) {                       \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, false, true>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, 0, true>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
       if (e != hipSuccess) return e;                                                                \
       attr_mask5.fetch_or(1u << (dev & 31), std::memory_order_release);                             \
     }                                                                                               \
-    hipLaunchKernelGGL((KERN<OM, G, S, false, true>), grid, block, shmem, s, a);                    \
+    hipLaunchKernelGGL((KERN<OM, G, S, 0, true>), grid, block, shmem, s, a);                        \
   } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
     if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 4); else if ((S) == 3) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 3); else if ((S) == 2) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 2); else WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 1); } \
-    else if (pipelined && a.dbg) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, S, true); \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
@@ -1003,6 +1007,29 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       default: WCA_LAUNCH_S(OM, G, 0); break; \
     }                                         \
   } while (0)
+  // diagnostic launches (tools/gemm_stamps.py; never the product path): s_memtime stamps (a.dbg) and / or the tile wrap, for the encoder's
+  // kernel forms only
+  if (a.dbg != nullptr || a.dbg_wrap_m > 0) {
+    if (!pipelined || a.dbg_wrap_n <= 0 != (a.dbg_wrap_m <= 0)) return hipErrorInvalidValue;
+#define WCA_LAUNCH_DIAG(OM, G, SW)                                                      \
+  do {                                                                                  \
+    if (a.dbg != nullptr) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, 1, 1, SW);          \
+    else WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, 1, 2, SW);                           \
+  } while (0)
+    if (splitw) {
+      if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, true);
+      else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, true);
+      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, true);
+      else return hipErrorInvalidValue;
+    } else {
+      if (a.out_mode == 0 && a.gelu) WCA_LAUNCH_DIAG(0, true, false);
+      else if (a.out_mode == 0) WCA_LAUNCH_DIAG(0, false, false);
+      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, false);
+      else return hipErrorInvalidValue;
+    }
+#undef WCA_LAUNCH_DIAG
+    return hipGetLastError();
+  }
   if (a.out_mode == 3) {
     // residual + LayerNorm epilogue: persistent 256 x 256 kernel only (every workgroup of a 256-row panel must be resident:
     // one workgroup per CU, grid <= CUs), N a multiple of 256; the caller falls back to out_mode 2 + launch_layernorm_f16

@@ -38,6 +38,7 @@ struct GemmArgs {
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
+  int dbg_wrap_m, dbg_wrap_n; // diagnostic builds only: tile coordinates taken modulo these (an L2-resident operand footprint; outputs collide)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
   // out_mode 3 only (the residual GEMMs of a transformer block, N = n_state <= 2048, a multiple of 256):
   const float* ln_gamma;   // [N]
@@ -102,6 +103,9 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s);  // attention_split.hip (launch_attention forwards a.split != 0 here)
+// diagnostic (process-wide, 0 in the product): leave single passes out of the encoder's three-pass attention -- bit 0 K_lo Q_hi, bit 1 K_hi Q_lo,
+// bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 12, 15 are instantiated
+void set_attention_split_drop(int mask);
 
 // ---------------------------------------------------------------- small ops (elementwise.hip)
 // ld_out: elements between output rows (0 = d). lo_off != 0: split output, hi = f16(y) at out, lo = f16(y - hi) at out + lo_off
