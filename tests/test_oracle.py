@@ -470,3 +470,50 @@ def test_ragged_oracle_fixture_structure_and_one_live_utterance():
     _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", "topk", 10)
     assert np.array_equal(np.asarray(st), gold["st_%d" % u]) and np.array_equal(np.asarray(en), gold["en_%d" % u])
 
+
+
+def test_round5_oracle_fixtures_structure_and_live_leg_b_utterance():
+    """The fixtures committed in round 5: the 700-utterance second leg of the headline configuration, ragged leg B
+    (the reference CLI's defaults, infer_ali.py:160-162: medfilt 7, aggr mean) and ragged leg A at whisper-large-v3 dimensions. Structure of
+    each (one start / end per word, monotone, chained, inside the audio), and the LIVE oracle re-derives leg B's shortest utterance."""
+    import importlib
+    import sys
+    from oracle import timing_ref, whisper_ref, tokenizer_ref
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_ragged
+    wca = importlib.import_module("whisper-char-alignment_amd")
+    syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
+    audio = importlib.import_module("whisper-char-alignment_amd.audio")
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g700 = np.load(os.path.join(here, "oracle_word_times_medium_peaky_700.npz"))
+    assert len(g700.files) == 3 * 700
+    n_bound = 0
+    for u in range(10301, 11001):
+        st, en, sc = g700["st_%d" % u], g700["en_%d" % u], g700["sc_%d" % u]
+        assert len(st) == len(en) == len(syn.synth_text(u, 64).split()) and sc.shape == (384,) and np.all(np.isfinite(sc))
+        assert np.all(np.diff(en) >= 0) and np.all(st[1:] == en[:-1]) and 0 <= st[0] and en[-1] <= 10.0
+        n_bound += 2 * len(st)
+    g333 = np.load(os.path.join(here, "oracle_word_times_medium_peaky.npz"))
+    n_bound += sum(2 * len(g333["st_%d" % u]) for u in list(range(100, 132)) + list(range(10000, 10301)))
+    assert n_bound == 21050   # 632 (ids 100-131) + 6 184 (ids 10000-10300) + 14 234 (ids 10301-11000): DESIGN.md's "20 418" are the last two
+    for name, ids in (("oracle_word_times_ragged_B.npz", range(20000, 20128)), ("oracle_word_times_ragged_A_large_v3.npz", range(21000, 21024))):
+        g = np.load(os.path.join(here, name))
+        assert len(g.files) == 2 * len(ids)
+        for u in ids:
+            ns, ch = parity_ragged.spec(u)
+            st, en = g["st_%d" % u], g["en_%d" % u]
+            assert len(st) == len(en) == len(syn.synth_text(u, ch).split())
+            assert np.all(np.diff(en) >= 0) and np.all(st[1:] == en[:-1]) and 0 <= st[0] and en[-1] <= ns / 16000.0 + 0.02
+    assert sum(2 * len(np.load(os.path.join(here, "oracle_word_times_ragged_A_large_v3.npz"))["st_%d" % u]) for u in range(21000, 21024)) == 498
+    gB = np.load(os.path.join(here, "oracle_word_times_ragged_B.npz"))
+    u = min(range(20000, 20128), key=lambda v: parity_ragged.spec(v)[0])
+    ns, ch = parity_ragged.spec(u)
+    dims = wca.dims_for("medium")
+    sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
+    tok = tokenizer_ref.CharTokenizer()
+    mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(syn.synth_audio(u, ns))), audio.mel_filters(80))
+    tt = tokenizer_ref.encode_char(syn.synth_text(u, ch), tok)
+    cfg = parity_ragged.LEGS["B"]
+    w, _ = timing_ref.get_attentions(mel, torch.tensor([*tok.sot_sequence, tok.no_timestamps, *tt, tok.eot]), whisper_ref.WhisperRef(sd, dims), ns // 320, cfg["medfilt"], 1.0)
+    _words, st, en, _m, _s = timing_ref.force_align(w, tt, tok, "char", cfg["aggr"], cfg["topk"])
+    assert np.array_equal(np.asarray(st), gB["st_%d" % u]) and np.array_equal(np.asarray(en), gB["en_%d" % u])
