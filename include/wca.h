@@ -50,6 +50,9 @@ extern "C" {
 typedef struct wca_engine wca_engine;
 
 typedef enum {
+  WCA_STATUS_PARTITIONED = 1, /* wca_engine_set_stream on a CU-partitioned engine: the stream was RECORDED (it becomes the engine's stream
+                               * again when the partition is lifted) but phase 1 stays on its CU-masked stream, which is not ordered with
+                               * the caller's: synchronise before and after each entry point (the Python binding does) */
   WCA_OK = 0,
   WCA_ERR_INVALID = -1,   /* bad argument / shape                                  */
   WCA_ERR_TOO_LONG = -2,  /* n_tok > 448 or max_frames > 1500 (infer_ali.py:79)    */
@@ -91,7 +94,12 @@ const char* wca_last_error(void);
 int wca_version(void);
 
 /* ---- engine lifetime ------------------------------------------------------------------------ */
+/* A new engine is in the CONTRACT precision mode (WCA_PRECISION_REFERENCE: every stage on (hi, lo) operand pairs = the fp32 forward of
+ * /root/reference/timing.py:58 to fp32 summation noise; see wca_set_precision). Since round 5 the fast f16-operand mode is the opt-in:
+ * wca_engine_create_ex(..., WCA_PRECISION_F16, ...) builds the engine directly in it (no wide arena is ever allocated), or switch later
+ * with wca_set_precision. */
 int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out);
+int wca_engine_create_ex(const wca_model_dims* dims, int device_ordinal, int max_batch, int precision_mode, wca_engine** out);
 void wca_engine_destroy(wca_engine* e);
 /* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the HIP default (null)
  * stream. Until this is called the engine runs on a private non-blocking stream of its own. */
@@ -103,6 +111,15 @@ int wca_engine_synchronize(wca_engine* e);
  * assets/mel_filters.npz). Call wca_finalize_weights once after the last tensor. */
 int wca_load_weight(wca_engine* e, const char* name, const void* host_ptr, int dtype, const int64_t* shape, int ndim);
 int wca_finalize_weights(wca_engine* e);
+/* Weight MATRICES (Linear / Conv1d weights, the token embedding) are stored f16, like every openai checkpoint at rest
+ * (/root/reference/infer_ali.py:36-37: whisper.load_model upcasts those f16 values to fp32 parameters); biases, LayerNorm parameters and
+ * positional embeddings stay fp32. An fp32 source tensor whose values are NOT f16-representable (a fine-tuned fp32 state dict) is rounded
+ * by that storage, and the pair arithmetic of the contract mode is then no longer the fp32 model's: wca_load_weight counts such elements
+ * per tensor (wca_weights_inexact: tensors, values, name of the first one), and while any precision site is on pairs every entry point
+ * that runs the model returns WCA_ERR_INVALID with that count -- never a silently narrower model. wca_set_allow_rounded_weights(e, 1) is
+ * the explicit opt-in to run on the rounded weights; the f16 mode (approximate by definition) always runs. */
+int wca_weights_inexact(wca_engine* e, long long* n_tensors_out, long long* n_values_out, char* first_name_out, int first_name_cap);
+int wca_set_allow_rounded_weights(wca_engine* e, int on);
 
 /* ---- hot path, one reference function per entry point ---------------------------------------- */
 
@@ -284,6 +301,7 @@ int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, c
  * w = the PLAIN [N][K] matrix, K the algorithmic depth. out_mode as above (0, 1, 2, 4; >> 8: 0 auto, 257, 258).
  * WCA_ERR_INVALID where that kernel does not apply (fewer than 192 256 x 256 tiles, K % 128 != 0): the engine then multiplies
  * the K-doubled operands through wca_test_gemm's path. */
+/* (wca_test_gemm_pairs: out_mode bits 20-27 = the persistent workgroups' start spread in units of 1024 cycles, an experiment) */
 int wca_test_gemm_pairs(wca_engine* e, const void* a2_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                         int N, int K, int gelu, int out_mode);
 /* x (f32 [M][N], read-modify-write) += A W^T + bias; xn (f16 [M][N]) = LayerNorm(x; gamma, beta, eps 1e-5): the residual
@@ -302,13 +320,23 @@ int wca_test_gemm_rows(wca_engine* e, const void* a_f16_dev, const float* x_f32_
  * ([4 blocks][8 waves][64 tiles][8] u64); development aid for tools/gemm_stamps.py, never used by the product.
  * out_mode: bits 0-7 as wca_test_gemm (0 / 2 / 4), bit 8 GELU, bit 9 pair operands (a = [M][hi(K) | lo(K)], plain w: the SPLITW form),
  * bits 12-15 / 16-19: when non-zero, tile coordinates are taken modulo these (m, n) -- an L2-resident operand footprint, outputs
- * collide; with the wrap set dbg_dev may be NULL (no stamps: plain timing of the wrapped launch) */
+ * collide; with the wrap set dbg_dev may be NULL (no stamps: plain timing of the wrapped launch); bits 20-21: 0 wrap operand and output
+ * addresses, 1 operand addresses only, 2 output addresses only */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
                           int out_mode, unsigned long long* dbg_dev);
 /* diagnostic, process-wide (the product never calls it; 0 = the contract's three passes per product): leave single MFMA passes out of the
- * encoder's pair attention -- bit 0 K_lo Q_hi, bit 1 K_hi Q_lo, bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 12, 15 exist.
+ * encoder's pair attention -- bit 0 K_lo Q_hi, bit 1 K_hi Q_lo, bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 9, 12, 15 exist.
  * tools/precision_ablation.py --attn-drop: the product-level ablation of timing.py:58's fp32 attention. */
 int wca_test_set_attn_split_drop(int mask);
+/* A/B and test switches of the library, process-wide (csrc/debug_switch.cpp; every default is the shipped choice and the product never calls
+ * this): "attn_split_variant" (1: pair attention on the 16x16x32 kernel everywhere), "attn_variant" (f16 attention: 1 / 3), "head_stats_general"
+ * (1: the general head-statistics kernel), "gemm_supertile" (m-panels per supertile), "ln_pair_v4", "fail_precision_alloc" (1: the next
+ * precision switch fails its allocation: the roll-back test), "gemm_dephase" (cycles), "attn_split_drop". The environment variable of the same
+ * meaning (WCA_ATTN_SPLIT_VARIANT, ...) is read ONCE, as the switch's initial value, never per launch. */
+int wca_test_set_switch(const char* name, int value);
+/* the [batch][n_text_layer * n_text_head] head selection scores (timing.py:13-43) of the LAST fused batch, after it was fetched (no batch in
+ * flight): tools/precision_ablation.py compares them with the oracle's */
+int wca_test_last_scores(wca_engine* e, int batch, float* scores_host);
 /* q,k,v [B][n][H*64] f16 device -> o [B][nq][H*64] f16; cap_dev [B][H][nq][cap_ld] f32 or NULL.
  * causal: bit 0 = causal mask; bits 8-9 = kernel variant (0 auto, 1 the 16x16x32-MFMA kernel, 2 the 32x32x16-MFMA
  * kernel that serves the encoder's un-masked self-attention = what auto picks, 3 the same with the row sums on the vector
@@ -366,7 +394,7 @@ int wca_last_kernel_ms(wca_engine* e, int site, int* n_launches, float* total_ms
 int wca_set_fuse_ln(wca_engine* e, int on);
 /* Arithmetic of the model forward (reference: timing.py:58, `model(mel.unsqueeze(0), tokens.unsqueeze(0))` -- an fp32
  * forward of a checkpoint whose weights are f16 at rest):
- *   WCA_PRECISION_F16 (default): GEMM / attention operands are rounded to f16 once (11 significant bits), accumulation,
+ *   WCA_PRECISION_F16 (opt-in since round 5: wca_engine_create_ex / wca_set_precision): GEMM / attention operands are rounded to f16 once (11 significant bits), accumulation,
  *     residual stream, LayerNorm, softmax and everything downstream fp32. Fastest; attention maps agree with the fp32
  *     reference to ~3e-3, which can move an ill-conditioned DTW path or swap two near-tied heads of the top-k selection.
  *   WCA_PRECISION_SPLIT: reference precision on the f16 matrix pipe. Every activation operand x travels as the pair
@@ -377,8 +405,8 @@ int wca_set_fuse_ln(wca_engine* e, int on);
  *     ~2.3x the MFMA work, twice the operand memory and a second copy of the weights ([N][2K]).
  * The greedy ASR pre-pass (wca_greedy_decode) computes in f16 in both modes, like whisper.decode's fp16 default.
  * Switching re-creates the activation arena: no batch may be in flight, encoded-but-unconsumed states are dropped. */
-/*   WCA_PRECISION_REFERENCE = WCA_PRECISION_SPLIT: the CONTRACT mode -- every site split. bench.py's `value` and the CLI default run
- *     in this mode. The per-site ablation on the 301-utterance parity leg (profiles/r04_precision_ablation.txt, tools/precision_ablation.py)
+/*   WCA_PRECISION_REFERENCE = WCA_PRECISION_SPLIT: the CONTRACT mode -- every site split. A new engine (wca_engine_create), bench.py's
+ *     `value` and the CLI run in this mode. The per-site ablation on the 301-utterance parity leg (profiles/r04_precision_ablation.txt, tools/precision_ablation.py)
  *     shows that nothing from the encoder blocks on can be left on single f16 operands: every smaller site set misses at least one
  *     utterance whose 10th / 11th oracle head scores are within 5e-5 of each other. Leaving only the log-mel and the conv stem on
  *     single operands changes no boundary on that leg and costs 1 % less, but moves the selection scores by 1e-4 relative
@@ -422,8 +450,10 @@ int wca_set_overlap(wca_engine* e, int on);
 /* EXPERIMENT (measured in profiles/r04_cu_partition.txt, off by default): phase2_cus > 0 (a multiple of 8) gives phase 2
  * of the alignment and the greedy decode loop CU-masked streams that own that many compute units (hipExtStreamCreateWithCUMask) and phase 1
  * (log-mel, encoder, cross-K/V) the rest, its persistent GEMM grids sized to match -- so that the HBM-bound decode kernels run BESIDE
- * the MFMA-bound encoder instead of queueing behind its persistent workgroups. 0 lifts the partition. While it is active
- * wca_engine_set_stream is ignored (the caller's stream has no mask): inputs must be complete before an entry point is called. */
+ * the MFMA-bound encoder instead of queueing behind its persistent workgroups. 0 lifts the partition (phase 1 returns to the stream the caller
+ * bound last). While it is active wca_engine_set_stream records the stream and returns WCA_STATUS_PARTITIONED (the caller's stream has no
+ * mask): inputs must be complete before an entry point is called. Not together with wca_set_fuse_ln (WCA_ERR_STATE). A failure while creating
+ * the masked streams leaves the previous partition (or none) in place. */
 int wca_set_cu_partition(wca_engine* e, int phase2_cus);
 /* Decoder GEMMs on few rows (a greedy-decode step of wca_greedy_decode: M = batch; batch-1 teacher-forced forwards):
  * fused != 0 (default): for up to 128 rows one few-row kernel per GEMM with the LayerNorm in its prologue, the KV-cache append in its

@@ -24,6 +24,20 @@ def lib(wca):
     return wca._lib.load()
 
 
+@pytest.fixture
+def switch(wca, lib):
+    """Sets process-wide A/B / test switches of libwca.so (wca_test_set_switch) and puts every one back to 0 after the test."""
+    used = set()
+
+    def set_switch(name, value):
+        used.add(name)
+        wca._lib.check(lib.wca_test_set_switch(name.encode(), int(value)))
+
+    yield set_switch
+    for name in used:
+        lib.wca_test_set_switch(name.encode(), 0)
+
+
 @pytest.fixture(scope="session")
 def fake_vocab(tmp_path_factory):
     """A tiktoken-format vocabulary with the right SIZE (50257 ranks: the 256 bytes + synthetic 4-letter tokens) so that

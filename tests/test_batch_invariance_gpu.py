@@ -83,7 +83,7 @@ def test_config1_medium_batch_sizes_1_2_64(wca):
     tok = tk.get_tokenizer(True, language="English")
     sizes = [1, 2, 64]
     # ---- alignment-like checkpoint, default (f16-operand) mode: identical frames at every batch size
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=64).load_state_dict(syn.aligned_state_dict(dims, seed=0))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=64, precision="f16").load_state_dict(syn.aligned_state_dict(dims, seed=0))
     opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=3)
     utts = _utts(syn, rt, tok, range(300, 308), 160000, 64)
     frames = {B: _frames_at_batch(model, tok, utts, B, 160000, 500, opts) for B in sizes}
@@ -95,7 +95,7 @@ def test_config1_medium_batch_sizes_1_2_64(wca):
     del model
     torch.cuda.empty_cache()
     # ---- seeded random weights (the bench's checkpoint): reported in the default mode, zero in the reference-precision mode
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=64).load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=64, precision="f16").load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
     utts = _utts(syn, rt, tok, list(range(100, 108)) + list(range(10000, 10008)), 160000, 64)
     frames = {B: _frames_at_batch(model, tok, utts, B, 160000, 500, opts) for B in sizes}
     _compare(frames, sizes, "configs[1] medium dims, random peaky weights, f16 mode")
@@ -114,7 +114,7 @@ def test_config3_large_v2_batch_sizes_1_2_8(wca):
     dims = wca.dims_for("large-v2")
     tok = tk.get_tokenizer(True, language="English")
     sizes = [1, 2, 8]
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=8).load_state_dict(syn.aligned_state_dict(dims, seed=0, frames_per_token=3.3))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=8, precision="f16").load_state_dict(syn.aligned_state_dict(dims, seed=0, frames_per_token=3.3))
     opts = model.make_opts(aggregation="topk", topk=10, sot_len=3, medfilt_width=7)
     utts = _utts(syn, rt, tok, range(900, 904), 480000, 443)
     assert all(len(u[1]) == 448 for u in utts)

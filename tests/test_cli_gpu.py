@@ -174,7 +174,7 @@ def test_infer_ali_pipeline_throughput(wca, tmp_path):
     scp = tmp_path / "big.scp"
     scp.write_text("".join(lines))
     dims = wca.dims_for("medium")
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(syn.random_state_dict(dims, seed=0))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B, precision="f16").load_state_dict(syn.random_state_dict(dims, seed=0))
     model.set_precision("reference")   # the CLI's default --forward_precision (the contract mode): both rates in the same arithmetic
     tok = tk.get_tokenizer(True, language="English")
     # reference rate: bench.py's loop (inputs resident in HBM, two batches in flight, host tail overlapped)
@@ -401,7 +401,7 @@ def test_rccl_collation_through_the_c_abi(wca):
     test_abi_collation_retry_is_collective), counters are summed, and shard.allgather_results(..., engine=) takes this path."""
     shard = _m("shard")
     dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, _register=False)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, _register=False, precision="f16")
     uid = wca.WhisperAMD.comm_unique_id()
     assert len(uid) == 128 and any(uid)
     model.comm_init(uid, 0, 1)

@@ -30,7 +30,7 @@ def _small_model(wca, max_batch=4):
     syn = _m("synthetic")
     dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
     sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
-    return dims, sd, wca.WhisperAMD(dims, device="cuda:0", max_batch=max_batch).load_state_dict(sd)
+    return dims, sd, wca.WhisperAMD(dims, device="cuda:0", max_batch=max_batch, precision="f16").load_state_dict(sd)
 
 
 def _oracle_times(sd, dims, pcm_f32, token_ids, sot_len, word_tokens, max_frames, medfilt, aggregation, topk):
@@ -160,7 +160,7 @@ def test_large_v3_shaped_forward_b1(wca):
     dims = wca.dims_for("large-v3")
     assert (dims.n_mels, dims.n_vocab, dims.n_audio_layer, dims.n_text_layer, dims.n_text_head) == (128, 51866, 32, 32, 20)
     sd = syn.random_state_dict(dims, seed=2, cross_qk_std=0.08)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, precision="f16").load_state_dict(sd)
     # the quirk (infer_ali.py:41): the reference builds the tokenizer WITHOUT num_languages, so a large-v3 run frames its text with
     # the 99-language special ids (transcribe 50359, no_timestamps 50363) although the v3 vocabulary has 100 languages (50360 / 50364);
     # the drop-in keeps that behaviour, and --n_mels must be 128 (infer_ali.py:159)

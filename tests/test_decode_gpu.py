@@ -36,7 +36,7 @@ def small(pkg):
     # tiny model, but the real multilingual vocabulary size so that every special-token id is meaningful
     dims = pkg.ModelDimensions(80, 1500, 256, 4, 2, 51865, 448, 256, 4, 2)
     sd = syn.random_state_dict(dims, seed=5)
-    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=4)
+    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=4, precision="f16")
     m.load_state_dict(sd)
     return m, sd, dims
 
@@ -167,7 +167,7 @@ def test_decode_modes_agree(pkg):
     streams bit for bit."""
     syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
     dims = pkg.ModelDimensions(80, 1500, 512, 8, 2, 51865, 448, 512, 8, 2)
-    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=20)
+    m = pkg.WhisperAMD(dims, device="cuda:0", max_batch=20, precision="f16")
     m.load_state_dict(syn.random_state_dict(dims, seed=11))
     decoding, tok, opts, sup, blank = _setup(pkg, dims)
     B, sample_len = 20, 10

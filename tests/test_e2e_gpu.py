@@ -21,7 +21,7 @@ def setup(wca):
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
     sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3, precision="f16").load_state_dict(sd)
     tok = tk.get_tokenizer(True, language="English")
     return dims, sd, model, tok
 
@@ -170,6 +170,37 @@ def test_cu_partition_changes_nothing_but_the_streams(wca, setup):
     jump4, sel4 = model.align_batch(*args)
     for j, s_ in ((jump1, sel1), (j2, s2), (j3, s3), (jump4, sel4)):
         assert np.array_equal(j, jump0) and np.array_equal(s_, sel0)
+    # after the lift the engine runs on TORCH'S CURRENT stream again, not on its private non-blocking one -- an entry
+    # point with device-side outputs and no trailing sync (log_mel) must be ordered with torch work on a side stream: the producer of its
+    # input is delayed by a long torch kernel on that stream, the consumer follows immediately
+    side = torch.cuda.Stream()
+    ref = model.log_mel(torch.from_numpy(pcm[:1]).cuda(), [len(utts[0][0])]).clone()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        big = torch.randn(4096, 4096, device="cuda")
+        for _ in range(20):
+            big = big @ big * 1e-3                 # ~100 ms of queued work ahead of the copy below
+        x = torch.zeros(1, smax, device="cuda")
+        x.copy_(torch.from_numpy(pcm[:1]).cuda(), non_blocking=True)
+        got = model.log_mel(x, [len(utts[0][0])])   # reads x on `side` (the bound stream): must see the copy
+        out = got.clone()
+    side.synchronize()
+    assert torch.equal(out, ref)
+    # while a partition is active a foreign stream is only recorded (WCA_STATUS_PARTITIONED), and fuse_ln is refused together with it
+    model.set_cu_partition(64)
+    try:
+        with pytest.raises(wca._lib.WcaError, match="partitioned"):
+            model.set_fuse_ln(True)
+        with torch.cuda.stream(side):
+            got2 = model.log_mel(x, [len(utts[0][0])]).clone()
+        side.synchronize()
+        assert torch.equal(got2, ref)
+    finally:
+        model.set_cu_partition(0)
+    model.set_fuse_ln(True)
+    with pytest.raises(wca._lib.WcaError, match="every CU"):
+        model.set_cu_partition(64)
+    model.set_fuse_ln(False)
 
 
 def test_too_long_is_rejected(wca, setup):
@@ -226,7 +257,7 @@ def test_layernorm_epilogue_fusion_equals_separate_launches(wca):
     dims = wca.ModelDimensions(80, 1500, 1024, 16, 3, 51865, 448, 1024, 16, 3)
     sd = syn.random_state_dict(dims, seed=4, cross_qk_std=0.08)
     B = 12
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B, precision="f16").load_state_dict(sd)
     tok = tk.get_tokenizer(True, language="English")
     utts = [_utt(syn, rt, tok, 300 + u, 96000, 40) for u in range(B)]
     pcm = torch.from_numpy(np.stack([u[0] for u in utts])).cuda()
@@ -255,7 +286,7 @@ def _gate_batch(wca):
     dims = wca.dims_for("medium")
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
     B = 64
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B, precision="f16").load_state_dict(sd)
     tok = tk.get_tokenizer(True, language="English")
     utts = [_utt(syn, rt, tok, u, 160000, 64) for u in GATE_IDS]
     assert all(len(u[3]) == 69 for u in utts)
@@ -368,7 +399,7 @@ def test_alignment_like_model_parity_medium_dims(wca):
     dims = wca.dims_for("medium")
     sd = syn.aligned_state_dict(dims, seed=0)
     B, n_ref = 64, 16
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B, precision="f16").load_state_dict(sd)
     ref = whisper_ref.WhisperRef(sd, dims)
     tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -405,7 +436,7 @@ def test_large_v3_shape_family(wca):
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(128, 1500, 1280, 20, 1, 51866, 448, 1280, 20, 1)
     sd = syn.random_state_dict(dims, seed=2, cross_qk_std=0.06)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2, precision="f16").load_state_dict(sd)
     tok = tk.get_tokenizer(True, language="English")
     pcm, text, tt, tokens = _utt(syn, rt, tok, 3, 48000, 24)
     mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 128, model=model)
@@ -494,14 +525,14 @@ def test_force_align_subword_mode(wca, fake_vocab):
     assert np.max(np.abs(np.asarray(en) - np.asarray(ren))) <= 0.02 + 1e-9
 
 
-def test_head_stats_lean_kernel_changes_no_bit_of_the_alignment(wca, monkeypatch):
+def test_head_stats_lean_kernel_changes_no_bit_of_the_alignment(wca, switch):
     """The fused path (capture -> head statistics -> top-k -> aggregation -> DTW) with the lean head-statistics kernel against the general one
-    (WCA_HEAD_STATS_GENERAL=1): selected heads in score order and jump frames identical, in both precision modes and for ragged lengths (the
+    (switch head_stats_general, wca_test_set_switch): selected heads in score order and jump frames identical, in both precision modes and for ragged lengths (the
     aggregation re-materialises the selected heads with the general kernel's arithmetic: row maxima and sums must agree exactly), and the
     step-by-step API's weights bit for bit."""
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=8).load_state_dict(syn.random_state_dict(dims, seed=4, cross_qk_std=0.08))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=8, precision="f16").load_state_dict(syn.random_state_dict(dims, seed=4, cross_qk_std=0.08))
     tok = tk.get_tokenizer(True, language="English")
     utts = [_utt(syn, rt, tok, 700 + i, 40000 + 23000 * i, 20 + 7 * i) for i in range(8)]
     n_max, smax = max(len(u[3]) for u in utts), max(len(u[0]) for u in utts)
@@ -516,12 +547,12 @@ def test_head_stats_lean_kernel_changes_no_bit_of_the_alignment(wca, monkeypatch
         model.set_precision(mode)
         for w in (3, 7):
             opts = model.make_opts(aggregation="topk", topk=5, sot_len=3, medfilt_width=w)
-            monkeypatch.setenv("WCA_HEAD_STATS_GENERAL", "1")
+            switch("head_stats_general", 1)
             jump0, sel0 = model.align_batch(pcm_d, n_samples, tarr_d, n_tok, frames, opts)
             mel = model.log_mel(pcm_d, n_samples)
             wb0, _ = model.get_attentions(mel, tarr_d, frames, medfilt_width=w, n_tok=n_tok, want_logits=False)
             wb0 = wb0.clone()
-            monkeypatch.delenv("WCA_HEAD_STATS_GENERAL")
+            switch("head_stats_general", 0)
             jump1, sel1 = model.align_batch(pcm_d, n_samples, tarr_d, n_tok, frames, opts)
             wb1, _ = model.get_attentions(mel, tarr_d, frames, medfilt_width=w, n_tok=n_tok, want_logits=False)
             assert np.array_equal(sel0, sel1) and np.array_equal(jump0, jump1), (mode, w)

@@ -30,7 +30,7 @@ def gold():
 def mods(wca):
     m = lambda n: importlib.import_module("whisper-char-alignment_amd." + n)  # noqa: E731
     dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-    eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1)  # weight-less engine: the ops below take no model
+    eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, precision="f16")  # weight-less engine: the ops below take no model
     return m("timing"), m("tokenizer").get_tokenizer(True, language="English"), eng
 
 

@@ -150,7 +150,7 @@ def test_product_refuses_to_run_without_gpu():
         pytest.skip("GPU present")
     wca = importlib.import_module("whisper-char-alignment_amd")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
-        wca.WhisperAMD(wca.dims_for("tiny"))
+        wca.WhisperAMD(wca.dims_for("tiny"), precision="f16")
     tm = _m("timing")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         tm.filter_attention(torch.rand(2, 2, 4, 8).softmax(-1), topk=1)

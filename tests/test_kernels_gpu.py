@@ -19,7 +19,7 @@ def _vp(t):
 def eng(wca):
     syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
     dims = wca.ModelDimensions(80, 1500, 384, 6, 2, 51865, 448, 384, 6, 2)
-    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2, precision="f16")
     m.load_state_dict(syn.random_state_dict(dims, seed=1))
     m._bind_stream()
     return m
@@ -620,7 +620,7 @@ def test_logmel_full_length_and_sample(eng, wca):
 @pytest.mark.parametrize("w", [1, 3, 5, 7, 9])
 @pytest.mark.parametrize("n,S,F", [(1, 1, 1), (3, 2, 2), (5, 70, 3), (4, 64, 63), (7, 64, 64), (6, 130, 65), (70, 512, 500), (9, 777, 777),
                                    (11, 1500, 1024), (5, 1500, 1500)])
-def test_head_stats_lean_kernel_bit_identical_to_general(eng, wca, monkeypatch, w, n, S, F):
+def test_head_stats_lean_kernel_bit_identical_to_general(eng, wca, switch, w, n, S, F):
     """`head_stats_fast_kernel` (postproc.hip: packed-f32 libm expf sequence, row-shared reciprocal refinement of the IEEE division, v_med3
     medians, no exec masking) must give the bits of the general kernel on every element: logits of wide dynamic range (rows whose smallest
     exponent argument lies below -68 take the plain-division branch, rows with -inf and with a 1e4 outlier included), every unrolled filter
@@ -639,9 +639,9 @@ def test_head_stats_lean_kernel_bit_identical_to_general(eng, wca, monkeypatch, 
         qk[0, 2, 1] = torch.linspace(0, -67.9 / scale, S)
         qk[0, 2, 2] = torch.linspace(-72 / scale, 0, S)
     qk = qk.cuda()
-    monkeypatch.setenv("WCA_HEAD_STATS_GENERAL", "1")
+    switch("head_stats_general", 1)
     ref = tm.attention_weights(qk, F, medfilt_width=w, qk_scale=scale).cpu()
-    monkeypatch.delenv("WCA_HEAD_STATS_GENERAL")
+    switch("head_stats_general", 0)
     out = tm.attention_weights(qk, F, medfilt_width=w, qk_scale=scale).cpu()
     assert torch.equal(out.view(torch.int32), ref.view(torch.int32)), (out - ref).abs().max().item()
     # and both are the softmax they claim to be

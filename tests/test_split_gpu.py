@@ -40,7 +40,7 @@ def _join(x2):
 def eng(wca):
     syn = importlib.import_module("whisper-char-alignment_amd.synthetic")
     dims = wca.ModelDimensions(80, 1500, 384, 6, 2, 51865, 448, 384, 6, 2)
-    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=2, precision="f16")
     m.load_state_dict(syn.random_state_dict(dims, seed=1))
     m._bind_stream()
     return m
@@ -152,15 +152,15 @@ def _attn_ref64(q, k, v, H, causal):
     (1, 2, 128, 64, 0, 0), (2, 2, 257, 129, 0, 0), (1, 3, 300, 1, 0, 0), (1, 2, 600, 130, 0, 0), (1, 1, 512, 64, 0, 0), (2, 1, 700, 128, 0, 0),
     (1, 2, 1030, 260, 0, 0)])
 @pytest.mark.parametrize("variant", [0, 1])
-def test_split_attention_is_fp32_accurate(eng, lib, wca, monkeypatch, B, H, nq, nk, causal, cap_cols, variant):
+def test_split_attention_is_fp32_accurate(eng, lib, wca, switch, B, H, nq, nk, causal, cap_cols, variant):
     """attn_split_kernel / attn_split32_kernel (three MFMA passes per product on hi / lo pairs, fp32 online softmax on the exact logits)
     against a float64 attention: output and captured logits at fp32 accuracy. A few large logits exercise the running-maximum update.
     variant 0: the launcher's choice (the 32x32x16 kernel for unmasked, capture-free calls of >= 64 query rows); 1: the 16x16x32 kernel
-    everywhere (WCA_ATTN_SPLIT_VARIANT=1)."""
+    everywhere (switch attn_split_variant = 1, wca_test_set_switch)."""
     if variant:
         if causal or cap_cols or nq < 64:
             pytest.skip("the 16x16x32 kernel is the launcher's choice here already")
-        monkeypatch.setenv("WCA_ATTN_SPLIT_VARIANT", str(variant))
+        switch("attn_split_variant", variant)
     g = torch.Generator().manual_seed(nq * 13 + nk)
     d = H * 64
     q = torch.randn(B, nq, d, generator=g)
@@ -216,7 +216,7 @@ def test_split_forward_vs_oracle_small_dims(wca):
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
     sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3, precision="f16").load_state_dict(sd)
     tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
     ref = whisper_ref.WhisperRef(sd, dims)
     pcm, text, tt, tokens = _utt(syn, rt, tok, 7, 80000, 40)
@@ -293,7 +293,7 @@ def test_split_mode_closes_the_headline_parity_gap(wca):
     B = 64
     ids = OFFENDER_IDS + list(range(100, 132))
     fill = (ids * ((B + len(ids) - 1) // len(ids)))[:B]
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=B, precision="f16").load_state_dict(sd)
     ref = whisper_ref.WhisperRef(sd, dims)
     tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
@@ -365,7 +365,7 @@ def test_precision_sites_seams_small_dims(wca):
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(80, 1500, 256, 4, 3, 51865, 448, 256, 4, 3)
     sd = syn.random_state_dict(dims, seed=5, cross_qk_std=0.08)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=3, precision="f16").load_state_dict(sd)
     tok = tk.get_tokenizer(True, language="English")
     ref = whisper_ref.WhisperRef(sd, dims)
     pcm, text, tt, tokens = _utt(syn, rt, tok, 7, 80000, 40)
@@ -431,14 +431,14 @@ def test_precision_sites_seams_small_dims(wca):
     del model
 
 
-def test_failed_precision_switch_leaves_a_working_engine(wca, monkeypatch):
+def test_failed_precision_switch_leaves_a_working_engine(wca, switch):
     """wca_set_precision allocates the NEW arena (and the K-doubled weight copies) before it releases the old ones and
-    commits the mode only when both allocations succeeded. With an allocation failure injected (WCA_TEST_FAIL_PRECISION_ALLOC) the switch
+    commits the mode only when both allocations succeeded. With an allocation failure injected (wca_test_set_switch("fail_precision_alloc", 1)) the switch
     must return WCA_ERR_HIP, the engine must stay in its previous mode with every arena pointer intact -- same maps bit for bit -- and a
     later switch must work; the same from the split mode back to f16."""
     syn, tk, rt, tm, audio = _mods()
     dims = wca.ModelDimensions(80, 1500, 256, 4, 2, 51865, 448, 256, 4, 2)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2).load_state_dict(syn.random_state_dict(dims, seed=9, cross_qk_std=0.08))
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2, precision="f16").load_state_dict(syn.random_state_dict(dims, seed=9, cross_qk_std=0.08))
     tok = tk.get_tokenizer(True, language="English")
     pcm, text, tt, tokens = _utt(syn, rt, tok, 3, 64000, 30)
     mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
@@ -448,19 +448,99 @@ def test_failed_precision_switch_leaves_a_working_engine(wca, monkeypatch):
         return tm.get_attentions(mel, tdev, model, tok, 200, medfilt_width=3)[0].cpu()
 
     w16 = maps()
-    monkeypatch.setenv("WCA_TEST_FAIL_PRECISION_ALLOC", "1")
+    switch("fail_precision_alloc", 1)
     with pytest.raises(wca._lib.WcaError, match="keeps its previous mode"):
         model.set_precision("split")
     assert model.precision == "f16" and torch.equal(maps(), w16)
-    monkeypatch.delenv("WCA_TEST_FAIL_PRECISION_ALLOC")
+    switch("fail_precision_alloc", 0)
     model.set_precision("split")
     wsp = maps()
     assert model.precision == "split" and (wsp - w16).abs().max().item() < 1e-2 and not torch.equal(wsp, w16)
-    monkeypatch.setenv("WCA_TEST_FAIL_PRECISION_ALLOC", "1")
+    switch("fail_precision_alloc", 1)
     with pytest.raises(wca._lib.WcaError, match="keeps its previous mode"):
         model.set_precision("f16")
     assert model.precision == "split" and torch.equal(maps(), wsp)
-    monkeypatch.delenv("WCA_TEST_FAIL_PRECISION_ALLOC")
+    switch("fail_precision_alloc", 0)
     model.set_precision("f16")
     assert torch.equal(maps(), w16)
     del model
+
+
+def test_new_engine_is_in_the_contract_mode(wca, lib):
+    """the safe mode is the constructor's. wca_engine_create and WhisperAMD() start with every site on pairs; the fast f16 mode
+    is the explicit opt-in (wca_engine_create_ex(..., WCA_PRECISION_F16) / WhisperAMD(precision='f16'))."""
+    import ctypes as C
+    dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=1)
+    assert m.precision == "split" and m.precision_sites[0] == ["logmel", "conv", "enc_gemm", "enc_attn", "cross_kv", "dec", "capture"]
+    m16 = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, precision="f16")
+    assert m16.precision == "f16" and m16.precision_sites[0] == []
+    cd = wca._lib.ModelDims(**__import__("dataclasses").asdict(dims))
+    h = C.c_void_p(0)
+    wca._lib.check(lib.wca_engine_create(C.byref(cd), 0, 1, C.byref(h)))
+    assert lib.wca_get_precision(h) == 1   # WCA_PRECISION_REFERENCE
+    lib.wca_engine_destroy(h)
+    h = C.c_void_p(0)
+    wca._lib.check(lib.wca_engine_create_ex(C.byref(cd), 0, 1, 0, C.byref(h)))
+    assert lib.wca_get_precision(h) == 0
+    lib.wca_engine_destroy(h)
+    with pytest.raises(wca._lib.WcaError):
+        wca._lib.check(lib.wca_engine_create_ex(C.byref(cd), 0, 1, 7, C.byref(h)))
+    del m, m16
+
+
+def test_fp32_checkpoint_that_is_not_f16_exact_is_never_run_silently_narrower(wca):
+    """VERDICT r4 item 4 (/root/reference/infer_ali.py:36-37: whisper.load_model upcasts the checkpoint to fp32 parameters, so a fine-tuned fp32
+    .pt runs in true fp32 there). The engine stores weight matrices f16; an fp32 state dict whose values are NOT f16-representable is
+    therefore rounded, and the contract mode must say so instead of running a narrower model: load_state_dict raises, the C ABI's entry
+    points return WCA_ERR_INVALID, `weights_inexact` counts what was rounded. With the explicit opt-in the engine computes exactly what the
+    f16-rounded checkpoint computes (bit for bit). An fp32 state dict whose values ARE f16-representable (an openai checkpoint upcast by
+    whisper.load_model) loads without complaint and gives the f16 checkpoint's maps bit for bit; the f16 mode always loads."""
+    syn, tk, rt, tm, audio = _mods()
+    dims = wca.ModelDimensions(80, 1500, 256, 4, 2, 51865, 448, 256, 4, 2)
+    sd32 = syn.random_state_dict(dims, seed=11, cross_qk_std=0.08, dtype=torch.float32)   # N(0, 0.02) fp32 draws: almost none is an f16 value
+    sd16 = {k: (v.half() if v.dtype == torch.float32 and ("weight" in k and v.ndim >= 2 and "positional" not in k) else v) for k, v in sd32.items()}
+    sd32_exact = {k: v.float() for k, v in sd16.items()}
+    tok = tk.get_tokenizer(True, language="English")
+    pcm, text, tt, tokens = _utt(syn, rt, tok, 5, 64000, 30)
+    tdev = torch.tensor(tokens).cuda()
+
+    def maps(model):
+        mel = audio.log_mel_spectrogram(audio.pad_or_trim(torch.from_numpy(pcm)), 80, model=model)
+        return tm.get_attentions(mel, tdev, model, tok, 200, medfilt_width=3)[0].cpu()
+
+    # the contract mode refuses (Python layer at load time, C ABI at run time)
+    m = wca.WhisperAMD(dims, device="cuda:0", max_batch=1)
+    with pytest.raises(ValueError, match="not f16-representable"):
+        m.load_state_dict(sd32)
+    n_t, n_v, first = m.weights_inexact
+    n_mats = sum(1 for k, v in sd32.items() if "weight" in k and v.ndim >= 2 and "positional" not in k)
+    assert n_t == n_mats and n_v > 0.9 * sum(v.numel() for k, v in sd32.items() if "weight" in k and v.ndim >= 2 and "positional" not in k) and first
+    with pytest.raises(wca._lib.WcaError, match="exact in f16"):
+        maps(m)                                     # (the weights are loaded and finalized: the C entry point itself refuses)
+    m.set_precision("f16")
+    w_f16mode = maps(m)                             # the f16 mode runs on them (approximate by definition)
+    assert torch.isfinite(w_f16mode).all()
+    del m
+    # opt-in: exactly the rounded checkpoint
+    m_allow = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd32, allow_rounded_weights=True)
+    assert m_allow.precision == "split" and m_allow.weights_inexact[0] == n_mats
+    m_16 = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd16)
+    assert m_16.weights_inexact == (0, 0, "")
+    w_allow, w_16 = maps(m_allow), maps(m_16)
+    assert torch.equal(w_allow, w_16)
+    # fp32 values that ARE f16-exact: no complaint, same bits; and re-loading exact tensors over inexact ones clears the record
+    m_ex = wca.WhisperAMD(dims, device="cuda:0", max_batch=1).load_state_dict(sd32_exact)
+    assert m_ex.weights_inexact == (0, 0, "") and torch.equal(maps(m_ex), w_16)
+    m_allow.load_state_dict(sd16)
+    assert m_allow.weights_inexact == (0, 0, "")
+    # against the fp32 oracle: the exact checkpoint at fp32 accuracy; the rounded fp32 one visibly further away (that is what is refused)
+    from oracle import timing_ref, whisper_ref
+    mel = whisper_ref.log_mel_spectrogram(whisper_ref.pad_or_trim(torch.from_numpy(pcm)), audio.mel_filters(80))
+    rw16, _ = timing_ref.get_attentions(mel, torch.tensor(tokens), whisper_ref.WhisperRef(sd16, dims), 200, 3, 1.0)
+    rw32, _ = timing_ref.get_attentions(mel, torch.tensor(tokens), whisper_ref.WhisperRef(sd32, dims), 200, 3, 1.0)
+    e_exact = (w_16 - rw16).abs().max().item()
+    e_rounded = (w_16 - rw32).abs().max().item()
+    print("maps vs the fp32 oracle: f16-exact checkpoint %.2e, fp32 checkpoint through rounded weights %.2e" % (e_exact, e_rounded))
+    assert e_exact < 5e-6 and e_rounded > 10 * e_exact
+    del m_allow, m_16, m_ex

@@ -47,7 +47,7 @@ def large_v2(wca):
     dims = wca.dims_for("large-v2")
     t0 = time.time()
     sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.05)
-    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device="cuda:0", max_batch=2, precision="f16").load_state_dict(sd)
     del sd
     _log("large-v2 dims (d=1280, 20 heads, 32+32 layers): engine + random weights ready in %.1f s" % (time.time() - t0))
     yield dims, model

@@ -29,7 +29,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 token_counts = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "16,24,32").split(",")]
 dims = wca.dims_for(os.environ.get("WCA_MODEL", "medium"))
-m = wca.WhisperAMD(dims, max_batch=B)
+m = wca.WhisperAMD(dims, max_batch=B, precision="f16")
 m.load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
 m.set_precision(os.environ.get("WCA_PRECISION", "f16"))
 print("forward precision:", m.precision, flush=True)

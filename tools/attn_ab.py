@@ -17,7 +17,7 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 variants = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2]
 H, S = 16, 1500
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 q = torch.randn(B, S, H * 64, device="cuda").half()
 k = torch.randn(B, S, H * 64, device="cuda").half()

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 wca = importlib.import_module("whisper-char-alignment_amd")
 vp = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 B, H, S = 32, 16, 1500
 q = torch.randn(B, S, H * 64, device="cuda").half()

@@ -19,7 +19,7 @@ sample_len = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 model_name = os.environ.get("WCA_MODEL", "medium")
 dims = wca.dims_for(model_name)
-m = wca.WhisperAMD(dims, max_batch=B)
+m = wca.WhisperAMD(dims, max_batch=B, precision="f16")
 m.load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.08))
 tok = tok_mod.get_tokenizer(True, language="en")
 initial = list(tok.sot_sequence)

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 wca = importlib.import_module("whisper-char-alignment_amd")
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)  # noqa: E731
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 M = 96000
 for name, N, K, gelu, mode in (("fc1+gelu", 4096, 1024, 1, 0), ("fc1 no gelu", 4096, 1024, 0, 0), ("qkv", 3072, 1024, 0, 0), ("fc2 rmw", 1024, 4096, 0, 2),

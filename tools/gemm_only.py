@@ -16,7 +16,7 @@ def vp(t):
 
 
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 M = 48000
 tile = int(sys.argv[1]) if len(sys.argv) > 1 else 256

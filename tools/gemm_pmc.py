@@ -18,7 +18,7 @@ def vp(t):
 
 n_launch = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 M = 96000
 # distinct kernel symbols: fc1 = <4, true, 1>, qkv = <4, false, 1>, fc2 = <2, false, 1> (the engine's fc2 is site 4: same code)

@@ -35,13 +35,14 @@ def timeit(fn, iters=10, warm=2):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, max_batch=1)
+eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
 eng._bind_stream()
 lib, chk = eng._lib, wca._lib.check
 M = B * 1500
 # name, N, K, out_mode bits (mode | gelu << 8), pair operands
 SHAPES = [("fc1", 4096, 1024, 4 | 256, True), ("qkv", 3072, 1024, 4, True), ("fc2", 1024, 4096, 2, True), ("out", 1024, 1024, 2, True),
           ("fc1", 4096, 1024, 0 | 256, False), ("qkv", 3072, 1024, 0, False), ("fc2", 1024, 4096, 2, False)]
+# (the stamp buffer holds 48 K steps per wave: the K = 4096 shapes' step stamps overlap the tile stamps -- read their timings, not their stamp rows)
 for name, n, k, mode, pairs in SHAPES:
     a = torch.randn(M, k, device="cuda") * 0.5
     hi = a.half()
@@ -52,7 +53,7 @@ for name, n, k, mode, pairs in SHAPES:
     flags = mode | (512 if pairs else 0)
     tag = "%s %s (M=%d N=%d K=%d)" % ("pair" if pairs else "f16 ", name, M, n, k)
     nk = (2 if pairs else 1) * k // 64
-    for wrap in (15, 2):   # 15 = no wrap (same diagnostic instantiation)
+    for wrap in ((15, 2) if len(sys.argv) <= 2 else ()):   # 15 = no wrap (same diagnostic instantiation); any second argument: timings only
         dbg = torch.zeros(4 * 8 * 64 * 8, dtype=torch.int64, device="cuda")
         fl = flags | (wrap << 12) | (wrap << 16)
         for _ in range(3):
@@ -84,8 +85,17 @@ for name, n, k, mode, pairs in SHAPES:
         t["product"] = min(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om))) for _ in range(3))
     else:
         t["product"] = min(timeit(lambda: chk(lib.wca_test_gemm(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om))) for _ in range(3))
-    for label, wr in (("diag no-wrap", 15), ("wrapped 2x2", 2), ("wrapped 1x1", 1)):
-        fl = flags | (wr << 12) | (wr << 16)
+    for label, wr, kind in (("diag no-wrap", 15, 0), ("wrapped 2x2", 2, 0), ("operands wrapped 2x2, real outputs", 2, 1), ("real operands, outputs wrapped 2x2", 2, 2), ("wrapped 1x1", 1, 0)):
+        fl = flags | (wr << 12) | (wr << 16) | (kind << 20)
         t[label] = min(timeit(lambda: chk(lib.wca_test_gemm_stamped(eng._h, vp(A), vp(w), vp(out), M, n, k, fl, None))) for _ in range(3))
     print("%s timing: " % tag + "  ".join("%s %.3f ms" % kv for kv in t.items()), flush=True)
+    if pairs:   # start spread of the persistent workgroups (product kernel): 0 / 1/8 / 1/4 / 1/2 / 1 tile period (~ nk x 3 400 cycles)
+        period = nk * 3400
+        td = {}
+        for frac in (0.0, 0.125, 0.25, 0.5, 1.0):
+            units = min(255, int(round(period * frac / 1024)))
+            for _ in range(2):
+                v = min(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om | (units << 20)))) for _ in range(3))
+                td[frac] = min(td.get(frac, 1e9), v)
+        print("%s start spread (fraction of a tile period): " % tag + "  ".join("%.3f: %.3f ms" % kv for kv in td.items()), flush=True)
     del a, hi, A, w, out

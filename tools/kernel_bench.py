@@ -34,7 +34,7 @@ def timeit(fn, iters=20, warm=3):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
     dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-    eng = wca.WhisperAMD(dims, max_batch=1)
+    eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
     eng._bind_stream()
     lib = eng._lib
     M = B * 1500

@@ -21,7 +21,7 @@ n_utts = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 dims = wca.dims_for(name)
 t0 = time.time()
 sd = syn.random_state_dict(dims, seed=0, cross_qk_std=qk_std)
-model = wca.WhisperAMD(dims, max_batch=1).load_state_dict(sd)
+model = wca.WhisperAMD(dims, max_batch=1, precision="f16").load_state_dict(sd)
 ref = whisper_ref.WhisperRef(sd, dims)
 tok, rtok = tk.get_tokenizer(True, language="English"), tokenizer_ref.CharTokenizer()
 torch.set_num_threads(min(os.cpu_count(), 16))

@@ -26,7 +26,7 @@ first = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 B, topk, medfilt, n_samples, chars = 64, 10, 3, 160000, 64
 dims = wca.dims_for("medium")
 sd = syn.random_state_dict(dims, seed=0, cross_qk_std=0.08)
-model = wca.WhisperAMD(dims, max_batch=B)
+model = wca.WhisperAMD(dims, max_batch=B, precision="f16")
 model.load_state_dict(sd)
 tok = tok_mod.get_tokenizer(True, language="en")
 opts = model.make_opts(aggregation="topk", topk=topk, sot_len=len(tok.sot_sequence), medfilt_width=medfilt, qk_scale=1.0)

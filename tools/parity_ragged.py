@@ -101,7 +101,7 @@ def main():
         return
 
     device = torch.device("cuda", 0)
-    model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch, precision="f16").load_state_dict(sd)
     tok = tok_mod.get_tokenizer(True, language="English")
     opts = model.make_opts(aggregation=cfg["aggr"], topk=cfg["topk"], sot_len=len(tok.sot_sequence), medfilt_width=cfg["medfilt"], qk_scale=1.0)
     batches = []

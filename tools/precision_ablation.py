@@ -120,7 +120,7 @@ def main():
         return
 
     device = torch.device("cuda", 0)
-    model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch).load_state_dict(sd)
+    model = wca.WhisperAMD(dims, device=str(device), max_batch=args.batch, precision="f16").load_state_dict(sd)
     tok = tok_mod.get_tokenizer(True, language="English")
     opts = model.make_opts(aggregation="topk", topk=args.topk, sot_len=len(tok.sot_sequence), medfilt_width=args.medfilt_width, qk_scale=1.0)
     n_samples = int(args.seconds * 16000)
@@ -153,12 +153,12 @@ def main():
         rows = sel
 
     drop_names = {0: "all six passes (contract)", 1: "without K_lo Q_hi", 2: "without K_hi Q_lo", 3: "S from K_hi Q_hi alone", 4: "without V_lo P_hi",
-                  8: "without V_hi P_lo", 12: "O from V_hi P_hi alone", 15: "one pass per product (pair operands elsewhere)"}
+                  8: "without V_hi P_lo", 9: "without K_lo Q_hi and V_hi P_lo", 12: "O from V_hi P_hi alone", 15: "one pass per product (pair operands elsewhere)"}
     if args.attn_drop:
         rows = [("attention passes: %s [mask %d]" % (drop_names.get(int(x), "?"), int(x)), "all", -1 - int(x)) for x in args.attn_drop.split(",")]
 
     lines = []
-    hdr = "%-46s %9s %9s | %7s %7s %7s | %5s %5s | %s" % ("sites (encoder bits from block)", "utt/s", "ms/step", "bounds", "within", "ident", "utts", "clean", "offenders (utt:boundaries off, same heads?, oracle k/k+1 gap)")
+    hdr = "%-46s %9s %9s | %7s %7s %7s | %5s %5s | %s" % ("sites (encoder bits from block)", "utt/s", "ms/step", "bounds", "within", "ident", "utts", "clean", "head-score deviation from the oracle (relative, all L x H heads) | offenders (utt:boundaries off, same heads?, oracle k/k+1 gap)")
     lines.append(hdr)
     print(hdr, flush=True)
     records = []
@@ -170,10 +170,18 @@ def main():
         # ---- parity
         total = within = ident = clean = 0
         offenders = []
+        sc_dev_max, sc_dev_sq, sc_n = 0.0, 0.0, 0
+        LH = dims.n_text_layer * dims.n_text_head
         for b in batches:
             jump, sel = model.align_batch(b["pcm"], [n_samples] * args.batch, b["tokens"], b["n_tok"], [n_samples // 320] * args.batch, opts)
+            sc_gpu = np.zeros((args.batch, LH), dtype=np.float32)
+            wca._lib.check(model._lib.wca_test_last_scores(model._h, args.batch, sc_gpu.ctypes.data_as(wca._lib._pf)))
             for j in range(b["n"]):
                 rst, ren, rsc = oracle[b["lo"] + j]
+                rel = np.abs(sc_gpu[j].astype(np.float64) - rsc) / np.abs(rsc)   # head selection scores (timing.py:13-43) against the oracle's, all L x H heads
+                sc_dev_max = max(sc_dev_max, float(rel.max()))
+                sc_dev_sq += float((rel ** 2).sum())
+                sc_n += rel.size
                 _w, st, en = timing.words_from_jump_frames(jump[j], b["tts"][j], tok, "char")
                 off = 0
                 for a_, r_ in ((np.asarray(st), rst), (np.asarray(en), ren)):
@@ -215,11 +223,13 @@ def main():
         el = time.perf_counter() - t0
         rate = args.batch * args.steps / el
         label = "%s%s" % (name, (" [from %d]" % first) if first else "")
-        line = "%-46s %9.1f %9.2f | %7d %7d %7d | %5d %5d | %s" % (label, rate, 1e3 * el / args.steps, total, within, ident, len(ids), clean, " ".join(offenders[:12]))
+        sc_rms = (sc_dev_sq / max(sc_n, 1)) ** 0.5
+        line = "%-46s %9.1f %9.2f | %7d %7d %7d | %5d %5d | score dev max %.1e rms %.1e | %s" % (label, rate, 1e3 * el / args.steps, total, within, ident, len(ids), clean, sc_dev_max, sc_rms, " ".join(offenders[:12]))
         lines.append(line)
         print(line, flush=True)
         records.append(dict(row=name, sites=sites, enc_first_layer=first, utt_per_s=rate, ms_per_step=1e3 * el / args.steps, boundaries=total, within_one_frame=within,
-                            identical=ident, utterances=len(ids), utterances_clean=clean, offenders=offenders))
+                            identical=ident, utterances=len(ids), utterances_clean=clean, offenders=offenders,
+                            score_rel_dev_max=sc_dev_max, score_rel_dev_rms=sc_rms))
     if args.attn_drop:
         wca._lib.check(model._lib.wca_test_set_attn_split_drop(0))
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -14,7 +14,7 @@ import test_split_gpu as T  # noqa: E402
 
 vp = T._vp
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1)
+eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, precision="f16")
 eng._bind_stream()
 for (B, H, nq, nk, causal, spike) in [(2, 3, 150, 200, 0, True), (2, 3, 150, 200, 0, False), (1, 1, 16, 64, 0, False), (1, 1, 16, 2, 0, False), (1, 1, 16, 17, 0, False)]:
     g = torch.Generator().manual_seed(nq * 13 + nk)

@@ -36,7 +36,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     only = sys.argv[3] if len(sys.argv) > 3 else ""
     dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-    eng = wca.WhisperAMD(dims, max_batch=1)
+    eng = wca.WhisperAMD(dims, max_batch=1, precision="f16")
     eng._bind_stream()
     lib, chk = eng._lib, wca._lib.check
     M = B * 1500
@@ -85,13 +85,13 @@ def main():
     qh, kh, vh = q.half(), k_.half(), v.half()
     o, o2 = torch.empty_like(qh), torch.empty_like(q2)
     t16, t3, t3o = [], [], []
-    for _ in range(reps):   # interleaved: f16, pair 32x32x16 (the launcher's choice), pair 16x16x32 (WCA_ATTN_SPLIT_VARIANT=1)
+    for _ in range(reps):   # interleaved: f16, pair 32x32x16 (the launcher's choice), pair 16x16x32 (switch attn_split_variant = 1)
         t16.append(timeit(lambda: chk(lib.wca_test_attention(eng._h, vp(qh), vp(kh), vp(vh), vp(o), None, 0, 0, B, H, S, S, 0))))
-        os.environ.pop("WCA_ATTN_SPLIT_VARIANT", None)
+        chk(lib.wca_test_set_switch(b"attn_split_variant", 0))
         t3.append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
-        os.environ["WCA_ATTN_SPLIT_VARIANT"] = "1"
+        chk(lib.wca_test_set_switch(b"attn_split_variant", 1))
         t3o.append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
-        os.environ.pop("WCA_ATTN_SPLIT_VARIANT", None)
+        chk(lib.wca_test_set_switch(b"attn_split_variant", 0))
     fl = 4.0 * B * H * S * S * 64
     print("attn enc B=%d H=%d S=%d  f16 %.3f ms (%.0f TF)  pair 32x32x16 %.3f ms (%.0f TF alg)  pair 16x16x32 %.3f ms (%.0f TF alg)"
           % (B, H, S, min(t16), fl / min(t16) / 1e9, min(t3), fl / min(t3) / 1e9, min(t3o), fl / min(t3o) / 1e9), flush=True)

@@ -18,7 +18,7 @@ syn, tk, rt, tm = m("synthetic"), m("tokenizer"), m("retokenize"), m("timing")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 dims = wca.dims_for("large-v2")
 t0 = time.time()
-model = wca.WhisperAMD(dims, max_batch=B).load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.05))
+model = wca.WhisperAMD(dims, max_batch=B, precision="f16").load_state_dict(syn.random_state_dict(dims, seed=0, cross_qk_std=0.05))
 print("setup %.1fs" % (time.time() - t0), flush=True)
 tok = tk.get_tokenizer(True, language="English")
 pcm = np.stack([syn.synth_audio(u, 480000) for u in range(B)])

@@ -13,7 +13,7 @@ wca = importlib.import_module("whisper-char-alignment_amd")
 lib = wca._lib.load()
 vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 dims = wca.ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1)
-eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1)
+eng = wca.WhisperAMD(dims, device="cuda:0", max_batch=1, precision="f16")
 eng._bind_stream()
 M = N = 128
 K = 64

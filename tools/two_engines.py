@@ -22,7 +22,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 24
 dims = wca.dims_for("medium")
 sd = syn.random_state_dict(dims, seed=0)
 tok = tk.get_tokenizer(True, language="English")
-engines = [wca.WhisperAMD(dims, max_batch=B).load_state_dict(sd) for _ in range(P)]
+engines = [wca.WhisperAMD(dims, max_batch=B, precision="f16").load_state_dict(sd) for _ in range(P)]
 pcm = torch.from_numpy(np.stack([syn.synth_audio(u) for u in range(B)])).cuda()
 rows = [[*tok.sot_sequence, tok.no_timestamps, *retok.encode(syn.synth_text(u, 64), tok, "char"), tok.eot] for u in range(B)]
 n_max = max(len(r) for r in rows)

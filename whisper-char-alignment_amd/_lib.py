@@ -52,11 +52,14 @@ SIGNATURES = {
     "wca_last_error": (C.c_char_p, []),
     "wca_version": (_i, []),
     "wca_engine_create": (_i, [C.POINTER(ModelDims), _i, _i, C.POINTER(_vp)]),
+    "wca_engine_create_ex": (_i, [C.POINTER(ModelDims), _i, _i, _i, C.POINTER(_vp)]),
     "wca_engine_destroy": (None, [_vp]),
     "wca_engine_set_stream": (_i, [_vp, _vp]),
     "wca_engine_synchronize": (_i, [_vp]),
     "wca_load_weight": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(_i64), _i]),
     "wca_finalize_weights": (_i, [_vp]),
+    "wca_weights_inexact": (_i, [_vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_char_p, _i]),
+    "wca_set_allow_rounded_weights": (_i, [_vp, _i]),
     "wca_log_mel": (_i, [_vp, _vp, _i64, _pi32, _i, _vp]),
     "wca_get_attentions": (_i, [_vp, _vp, _vp, _i, _i, _pi32, _pi32, _i, _f, _vp, _vp]),
     "wca_median_filter": (_i, [_vp, _vp, _vp, _i64, _i, _i]),
@@ -79,6 +82,8 @@ SIGNATURES = {
     "wca_test_gemm_ln": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "wca_test_gemm_stamped": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "wca_test_set_attn_split_drop": (_i, [_i]),
+    "wca_test_set_switch": (_i, [C.c_char_p, _i]),
+    "wca_test_last_scores": (_i, [_vp, _i, _pf]),
     "wca_test_gemm_pairs": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i]),
     "wca_test_attention": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),
     "wca_test_attention_split": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i]),

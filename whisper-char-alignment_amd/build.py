@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libwca.so")
-SOURCES = ["gemm.hip", "gemm_rows.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip", "flac.cpp"]
+SOURCES = ["gemm.hip", "gemm_rows.hip", "attention.hip", "attention_split.hip", "elementwise.hip", "logmel.hip", "postproc.hip", "dtw.hip", "decode.hip", "engine.hip", "flac.cpp", "debug_switch.cpp"]
 HEADERS = ["kernels.h", "wca_common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "wca.h")]
 # -amdgpu-mfma-vgpr-form: keep MFMA accumulators in VGPRs (the softmax / epilogue VALU code reads them
 # directly; the AGPR form costs a v_accvgpr_read/write pair per element in the attention loop)
@@ -50,7 +50,7 @@ def build_lib(force=False, verbose=True):
     def cc(job):
         s, o = job
         if s.endswith(".cpp"):  # host-only source (audio file decoding): plain C++, no device code
-            cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-Wall", "-x", "c++", "-c", s, "-o", o]
+            cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-x", "c++", "-c", s, "-o", o]
         else:
             cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -846,8 +846,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
   const size_t shmem = 3 * 2 * TILE * sizeof(half_t);  // 48 KiB
   // encoder self-attention (no mask, no capture, long rows): the 32x32x16 kernel; a.variant 1 forces the 16x16x32 one, 2 the
   // 32x32x16 one (tests)
-  static const int env_variant = getenv("WCA_ATTN_VARIANT") ? atoi(getenv("WCA_ATTN_VARIANT")) : 0;  // debugging aid
-  const int variant = a.variant ? a.variant : env_variant;
+  const int variant = a.variant ? a.variant : debug_switch(DBG_ATTN_VARIANT);  // debugging aid
   const bool use32 = !a.causal && !cap && (a.o_rs % 8) == 0 && variant != 1 && (a.nq >= 64 || variant >= 2);
   if (use32) {
     dim3 g32(((a.nq + 127) / 128) * a.H * a.B), b32(256);

@@ -14,7 +14,6 @@
 // with the slot that tile kt + 1 is then requested into). Scores transposed (S^T = K Q^T) so that a query row is a lane column;
 // textbook online softmax in fp32 on the RAW scores (no deferred maximum, no pre-scaled Q: nothing is rounded to f16 before
 // the exponential); P is split like every other operand.
-#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -785,11 +784,7 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
     }
 }
 
-std::atomic<int> g_attn_split_drop{0};
-
 }  // namespace
-
-void set_attention_split_drop(int mask) { g_attn_split_drop.store(mask & 15, std::memory_order_relaxed); }
 
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
   if (a.nq <= 0 || a.B <= 0) return hipSuccess;
@@ -807,9 +802,7 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_split_kernel<C, P, W>), dim3(((a.nq + (W) * 32 - 1) / ((W) * 32)) * a.H * a.B), dim3((W) * 64), shmem, s, a); \
   } while (0)
   // the encoder form (no mask, no capture) on the 32x32x16 kernel; AttnArgs.variant 1 (tests / A-B: WCA_ATTN_SPLIT_VARIANT=1) keeps the 16x16x32 one
-  const char* ev = std::getenv("WCA_ATTN_SPLIT_VARIANT");
-  const int env_variant = ev ? atoi(ev) : 0;
-  const int variant = a.variant ? a.variant : env_variant;
+  const int variant = a.variant ? a.variant : debug_switch(DBG_ATTN_SPLIT_VARIANT);
   if (!a.causal && !cap && a.nq >= 64 && variant != 1 && (a.o_rs % 8) == 0 && (a.o_lo % 8) == 0) {
 #define WCA_LAUNCH_A32(D)                                                                                                             \
   do {                                                                                                                                \
@@ -817,13 +810,14 @@ hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;                                                                                                    \
     hipLaunchKernelGGL(attn_split32_kernel<D>, dim3(((a.nq + 127) / 128) * a.H * a.B), dim3(256), shmem, s, a);                       \
   } while (0)
-    switch (g_attn_split_drop.load(std::memory_order_relaxed)) {   // 0 in the product; the other forms are the ablation's (wca_test_set_attn_split_drop)
+    switch (debug_switch(DBG_ATTN_SPLIT_DROP)) {   // 0 in the product; the other forms are the ablation's (wca_test_set_attn_split_drop)
       case 0: WCA_LAUNCH_A32(0); break;
       case 1: WCA_LAUNCH_A32(1); break;
       case 2: WCA_LAUNCH_A32(2); break;
       case 3: WCA_LAUNCH_A32(3); break;
       case 4: WCA_LAUNCH_A32(4); break;
       case 8: WCA_LAUNCH_A32(8); break;
+      case 9: WCA_LAUNCH_A32(9); break;
       case 12: WCA_LAUNCH_A32(12); break;
       case 15: WCA_LAUNCH_A32(15); break;
       default: return hipErrorInvalidValue;

@@ -226,7 +226,7 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
     else hipLaunchKernelGGL((KERN<NV, false>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off);                 \
   } while (0)
   // pair output on rows of >= 512 elements with 16-byte aligned halves: the eight-elements-per-lane kernel (16-byte stores)
-  static const bool pair_v8 = getenv("WCA_LN_PAIR_V4") == nullptr;   // (WCA_LN_PAIR_V4=1: the four-wide kernel, for the A/B)
+  const bool pair_v8 = debug_switch(DBG_LN_PAIR_V4) == 0;   // (switch ln_pair_v4: the four-wide kernel, for the A/B)
   if (lo_off && pair_v8 && d >= 512 && (d % 256) == 0 && (ld_out & 7) == 0 && (lo_off & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
     switch (d) {
       case 512: hipLaunchKernelGGL((layernorm_pair_v8_kernel<2>), grid, block, 0, s, x, gamma, beta, out, rows, eps, ld_out, lo_off); return hipGetLastError();

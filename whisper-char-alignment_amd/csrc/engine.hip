@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <set>
 #include <string>
 #include <vector>
@@ -131,6 +132,8 @@ struct wca_engine {
   bool have_filters = false;
   bool profiling = false;
   std::set<std::string> loaded;
+  std::map<std::string, size_t> inexact;  // tensors stored as f16 whose fp32 source values were NOT f16-representable: name -> count of rounded elements
+  bool allow_rounded = false;             // wca_set_allow_rounded_weights: run pair sites on such (rounded) weights although that is not the reference's arithmetic
 
   // ---- weights
   char* wslab = nullptr;
@@ -236,7 +239,9 @@ struct wca_engine {
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   int part_cus = 0;          // wca_set_cu_partition: > 0 = phase 2 / the decode loop own that many CUs (CU-masked streams), phase 1 the rest
   hipStream_t part_s1 = nullptr, part_s2 = nullptr, part_s3 = nullptr;  // the masked streams: they REPLACE stream / stream2 / stream3 while active
-  hipStream_t saved_s2 = nullptr, saved_s3 = nullptr;                   // ... and the engine's own ones come back when the partition is lifted
+  hipStream_t saved_s2 = nullptr, saved_s3 = nullptr;
+  hipStream_t user_stream = nullptr;   // the stream the caller bound last (wca_engine_set_stream), also while a partition is active
+  bool user_stream_set = false;                   // ... and the engine's own ones come back when the partition is lifted
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
                              // back to back, not concurrently -- 3.86 vs 3.90 ms per step -- so one stream is the default)
@@ -604,11 +609,20 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
 }
 
 // upload helpers: convert host tensor (f32 or f16) into device f16 / f32
-int put_f16(half_t* dst, const void* src, int dtype, size_t n) {
+// Every weight matrix is f16 AT REST here, like every openai checkpoint ("weights stored fp16, loaded into fp32 params",
+// /root/reference/infer_ali.py:36-37), which is what makes A W^T exact-operand arithmetic in the pair mode. An fp32 source whose values
+// are not f16-representable (a fine-tuned fp32 state dict) is ROUNDED here: *n_inexact counts those elements (NaN == NaN for this purpose);
+// wca_load_weight records them per tensor and the pair sites refuse to run on such weights unless the caller opted in (check_ready).
+int put_f16(half_t* dst, const void* src, int dtype, size_t n, size_t* n_inexact) {
   std::vector<half_t> tmp(n);
   if (dtype == WCA_DTYPE_F32) {
     const float* s = static_cast<const float*>(src);
-    for (size_t i = 0; i < n; ++i) tmp[i] = (half_t)s[i];
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+      tmp[i] = (half_t)s[i];
+      bad += ((float)tmp[i] != s[i]) && (s[i] == s[i]);
+    }
+    *n_inexact += bad;
   } else {
     memcpy(tmp.data(), src, n * sizeof(half_t));
   }
@@ -631,11 +645,18 @@ inline float host_val(const void* src, int dtype, size_t i) {
 }
 
 // conv weight [out][in][3] -> f16 [out][kpad] with column tap*in + c
-int put_conv(half_t* dst, const void* src, int dtype, int out, int in, int kpad) {
+int put_conv(half_t* dst, const void* src, int dtype, int out, int in, int kpad, size_t* n_inexact) {
   std::vector<half_t> tmp((size_t)out * kpad, (half_t)0.f);
+  size_t bad = 0;
   for (int n = 0; n < out; ++n)
     for (int c = 0; c < in; ++c)
-      for (int t = 0; t < 3; ++t) tmp[(size_t)n * kpad + t * in + c] = (half_t)host_val(src, dtype, ((size_t)n * in + c) * 3 + t);
+      for (int t = 0; t < 3; ++t) {
+        const float v = host_val(src, dtype, ((size_t)n * in + c) * 3 + t);
+        const half_t h = (half_t)v;
+        tmp[(size_t)n * kpad + t * in + c] = h;
+        bad += ((float)h != v) && (v == v);
+      }
+  *n_inexact += bad;
   HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice));
   return WCA_OK;
 }
@@ -647,33 +668,33 @@ size_t numel(const int64_t* shape, int ndim) {
 }
 
 int load_block_tensor(wca_engine* e, LayerW& l, bool is_dec, int li, const std::string& rest, const void* p, int dtype,
-                      size_t n, int d) {
+                      size_t n, int d, size_t* n_inexact) {
   const size_t dd = (size_t)d * d;
   auto expect = [&](size_t want) -> bool { return n == want; };
 #define WANT(cnt) \
   if (!expect(cnt)) return fail(WCA_ERR_INVALID, "weight %s: expected %zu elements, got %zu", rest.c_str(), (size_t)(cnt), n)
-  if (rest == "attn.query.weight") { WANT(dd); return put_f16(l.qkv_w, p, dtype, n); }
+  if (rest == "attn.query.weight") { WANT(dd); return put_f16(l.qkv_w, p, dtype, n, n_inexact); }
   if (rest == "attn.query.bias") { WANT(d); return put_f32(l.qkv_b, p, dtype, n); }
-  if (rest == "attn.key.weight") { WANT(dd); return put_f16(l.qkv_w + dd, p, dtype, n); }
-  if (rest == "attn.value.weight") { WANT(dd); return put_f16(l.qkv_w + 2 * dd, p, dtype, n); }
+  if (rest == "attn.key.weight") { WANT(dd); return put_f16(l.qkv_w + dd, p, dtype, n, n_inexact); }
+  if (rest == "attn.value.weight") { WANT(dd); return put_f16(l.qkv_w + 2 * dd, p, dtype, n, n_inexact); }
   if (rest == "attn.value.bias") { WANT(d); return put_f32(l.qkv_b + 2 * d, p, dtype, n); }
-  if (rest == "attn.out.weight") { WANT(dd); return put_f16(l.out_w, p, dtype, n); }
+  if (rest == "attn.out.weight") { WANT(dd); return put_f16(l.out_w, p, dtype, n, n_inexact); }
   if (rest == "attn.out.bias") { WANT(d); return put_f32(l.out_b, p, dtype, n); }
   if (rest == "attn_ln.weight") { WANT(d); return put_f32(l.ln1_g, p, dtype, n); }
   if (rest == "attn_ln.bias") { WANT(d); return put_f32(l.ln1_b, p, dtype, n); }
-  if (rest == "mlp.0.weight") { WANT(4 * dd); return put_f16(l.fc1_w, p, dtype, n); }
+  if (rest == "mlp.0.weight") { WANT(4 * dd); return put_f16(l.fc1_w, p, dtype, n, n_inexact); }
   if (rest == "mlp.0.bias") { WANT(4 * (size_t)d); return put_f32(l.fc1_b, p, dtype, n); }
-  if (rest == "mlp.2.weight") { WANT(4 * dd); return put_f16(l.fc2_w, p, dtype, n); }
+  if (rest == "mlp.2.weight") { WANT(4 * dd); return put_f16(l.fc2_w, p, dtype, n, n_inexact); }
   if (rest == "mlp.2.bias") { WANT(d); return put_f32(l.fc2_b, p, dtype, n); }
   if (rest == "mlp_ln.weight") { WANT(d); return put_f32(l.ln2_g, p, dtype, n); }
   if (rest == "mlp_ln.bias") { WANT(d); return put_f32(l.ln2_b, p, dtype, n); }
   if (is_dec) {
-    if (rest == "cross_attn.query.weight") { WANT(dd); return put_f16(l.cq_w, p, dtype, n); }
+    if (rest == "cross_attn.query.weight") { WANT(dd); return put_f16(l.cq_w, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.query.bias") { WANT(d); return put_f32(l.cq_b, p, dtype, n); }
-    if (rest == "cross_attn.key.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li) * dd, p, dtype, n); }
-    if (rest == "cross_attn.value.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li + 1) * dd, p, dtype, n); }
+    if (rest == "cross_attn.key.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li) * dd, p, dtype, n, n_inexact); }
+    if (rest == "cross_attn.value.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li + 1) * dd, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.value.bias") { WANT(d); return put_f32(e->kv_b + (size_t)(2 * li + 1) * d, p, dtype, n); }
-    if (rest == "cross_attn.out.weight") { WANT(dd); return put_f16(l.co_w, p, dtype, n); }
+    if (rest == "cross_attn.out.weight") { WANT(dd); return put_f16(l.co_w, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.out.bias") { WANT(d); return put_f32(l.co_b, p, dtype, n); }
     if (rest == "cross_attn_ln.weight") { WANT(d); return put_f32(l.lnc_g, p, dtype, n); }
     if (rest == "cross_attn_ln.bias") { WANT(d); return put_f32(l.lnc_b, p, dtype, n); }
@@ -1086,6 +1107,17 @@ int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, c
 int check_ready(wca_engine* e) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   if (!e->finalized) return fail(WCA_ERR_STATE, "weights not finalized (call wca_finalize_weights)");
+  // the pair sites compute the reference's fp32 forward only on weights that are EXACT in f16 (every openai checkpoint); never run a
+  // narrower model silently: refuse, unless the caller accepted the rounding
+  if (e->sites != 0 && !e->inexact.empty() && !e->allow_rounded) {
+    size_t tot = 0;
+    for (const auto& kv : e->inexact) tot += kv.second;
+    return fail(WCA_ERR_INVALID,
+                "the reference-precision mode needs weights that are exact in f16 (f16 at rest, like openai checkpoints): %zu tensor(s) hold %zu "
+                "fp32 value(s) that f16 storage rounded (first: %s, %zu values). Re-load an f16 checkpoint, call wca_set_allow_rounded_weights(e, 1) "
+                "to run the pair arithmetic on the ROUNDED weights (not the fp32 model's arithmetic), or wca_set_precision(e, WCA_PRECISION_F16)",
+                e->inexact.size(), tot, e->inexact.begin()->first.c_str(), e->inexact.begin()->second);
+  }
   HIPCHK(hipSetDevice(e->device));
   return ensure_split_weights(e);  // split mode: the K-doubled weight copies are current (no-op otherwise)
 }
@@ -1337,7 +1369,12 @@ const char* wca_last_error(void) { return g_err.c_str(); }
 int wca_version(void) { return 1; }
 
 int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out) {
+  return wca_engine_create_ex(dims, device_ordinal, max_batch, WCA_PRECISION_REFERENCE, out);   // the CONTRACT mode is the default (round 5)
+}
+
+int wca_engine_create_ex(const wca_model_dims* dims, int device_ordinal, int max_batch, int precision_mode, wca_engine** out) {
   if (!dims || !out) return fail(WCA_ERR_INVALID, "null argument");
+  if (precision_mode != WCA_PRECISION_F16 && precision_mode != WCA_PRECISION_REFERENCE) return fail(WCA_ERR_INVALID, "precision mode %d", precision_mode);
   if (max_batch < 1 || max_batch > 256) return fail(WCA_ERR_INVALID, "max_batch %d outside [1,256]", max_batch);
   const wca_model_dims& D = *dims;
   if (D.n_audio_ctx != N_CTX || D.n_text_ctx != MAX_TOK) return fail(WCA_ERR_INVALID, "n_audio_ctx must be 1500 and n_text_ctx 448");
@@ -1366,6 +1403,16 @@ int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_ba
   HIPCHK(hipMalloc((void**)&e->wslab, e->wslab_bytes));
   HIPCHK(hipMemset(e->wslab, 0, e->wslab_bytes));
   layout_weights(e, e->wslab);
+  if (precision_mode == WCA_PRECISION_REFERENCE) {   // born in the contract mode: the wide arena and the K-doubled weight copies from the start
+    e->split = true;
+    e->sites = (unsigned)WCA_PSITE_ALL;
+    e->enc_from = 0;
+    const size_t wbytes = layout_split_weights(e, nullptr);
+    HIPCHK(hipMalloc((void**)&e->wslab2, wbytes));
+    HIPCHK(hipMemset(e->wslab2, 0, wbytes));
+    layout_split_weights(e, e->wslab2);
+    e->sw_dirty = true;
+  }
   const size_t abytes = layout_arena(e, nullptr);
   HIPCHK(hipMalloc((void**)&e->aslab, abytes));
   HIPCHK(hipMemset(e->aslab, 0, abytes));  // zero pad rows of mel_tm / h1pad and all slack
@@ -1445,8 +1492,12 @@ void wca_engine_destroy(wca_engine* e) {
 
 int wca_engine_set_stream(wca_engine* e, void* hip_stream) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
-  if (e->part_cus > 0) return WCA_OK;   // CU-partitioned engine (wca_set_cu_partition): phase 1 stays on its masked stream
-  e->stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream, which is what torch's default stream is
+  e->user_stream = (hipStream_t)hip_stream;  // NULL is the HIP default (null) stream, which is what torch's default stream is
+  e->user_stream_set = true;
+  // CU-partitioned engine (wca_set_cu_partition): phase 1 stays on its masked stream, which is NOT ordered with the caller's stream
+  // (WCA_STATUS_PARTITIONED tells the binding to synchronise around its calls); the stream recorded here is restored when the partition is lifted
+  if (e->part_cus > 0) return WCA_STATUS_PARTITIONED;
+  e->stream = e->user_stream;
   return WCA_OK;
 }
 
@@ -1552,7 +1603,7 @@ int wca_set_precision_sites(wca_engine* e, unsigned mask, int enc_first_layer) {
     }
     if (he == hipSuccess) he = hipMemset(na, 0, abytes);  // zero pad rows of mel_tm / h1pad, counters, flags and all slack
     if (he == hipSuccess && nw) he = hipMemset(nw, 0, wbytes);  // K padding of the conv1 copy stays zero
-    if (he == hipSuccess && std::getenv("WCA_TEST_FAIL_PRECISION_ALLOC")) he = hipErrorOutOfMemory;  // fault injection for the test of the path below
+    if (he == hipSuccess && debug_switch(DBG_FAIL_PRECISION_ALLOC)) he = hipErrorOutOfMemory;  // fault injection (wca_test_set_switch) for the test of the path below
     if (he != hipSuccess) {
       if (na) (void)hipFree(na);
       if (nw) (void)hipFree(nw);
@@ -1607,6 +1658,8 @@ int wca_get_precision(wca_engine* e) {
 
 int wca_set_fuse_ln(wca_engine* e, int on) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  if (on && e->part_cus > 0)
+    return fail(WCA_ERR_STATE, "the LayerNorm epilogue fusion needs one resident workgroup per CU of the whole device: not available while the CUs are partitioned (wca_set_cu_partition)");
   e->fuse_ln = on != 0;
   return WCA_OK;
 }
@@ -1615,29 +1668,45 @@ int wca_set_cu_partition(wca_engine* e, int phase2_cus) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   if (phase2_cus < 0 || phase2_cus >= e->n_cu || (phase2_cus & 7)) return fail(WCA_ERR_INVALID, "phase2_cus %d: a multiple of 8 in [0, %d)", phase2_cus, e->n_cu);
   if (e->enq_count != e->fetch_count || !e->enc_q.empty()) return fail(WCA_ERR_STATE, "fetch / consume the batches in flight before changing the CU partition");
+  if (phase2_cus > 0 && e->fuse_ln)
+    return fail(WCA_ERR_STATE, "the LayerNorm epilogue fusion (wca_set_fuse_ln) needs every CU of the device: switch it off before partitioning the CUs");
   HIPCHK(hipSetDevice(e->device));
   HIPCHK(hipDeviceSynchronize());
-  if (e->part_s1) {
-    e->stream = e->own_stream;
+  // the masked streams of the NEW partition are created first and committed only when all three exist (a failure half way
+  // used to leave part_s1 set with nothing saved)
+  hipStream_t ns[3] = {nullptr, nullptr, nullptr};
+  if (phase2_cus > 0) {
+    // mask bit i = CU i of the device's enumeration; the round-robin of mask bits over the 8 XCDs gives both partitions CUs on every XCD
+    const int words = (e->n_cu + 31) / 32;
+    std::vector<uint32_t> m1(words, 0u), m2(words, 0u);
+    for (int i = 0; i < e->n_cu; ++i) (i < phase2_cus ? m2 : m1)[i >> 5] |= 1u << (i & 31);
+    for (int i = 0; i < 3; ++i) {
+      const hipError_t he = hipExtStreamCreateWithCUMask(&ns[i], (uint32_t)words, (i == 0 ? m1 : m2).data());
+      if (he != hipSuccess) {
+        for (int j = 0; j < i; ++j) (void)hipStreamDestroy(ns[j]);
+        (void)hipGetLastError();
+        return fail(WCA_ERR_HIP, "CU-masked stream %d: %s; the engine keeps its previous partition", i, hipGetErrorString(he));
+      }
+    }
+  }
+  if (e->part_s1) {   // lift the present partition: phase 1 goes back to the stream the CALLER bound (not to the engine's private one)
+    e->stream = e->user_stream_set ? e->user_stream : e->own_stream;
     e->stream2 = e->saved_s2;
     e->stream3 = e->saved_s3;
     (void)hipStreamDestroy(e->part_s1);
     (void)hipStreamDestroy(e->part_s2);
     (void)hipStreamDestroy(e->part_s3);
     e->part_s1 = e->part_s2 = e->part_s3 = nullptr;
+    e->saved_s2 = e->saved_s3 = nullptr;
   }
   e->part_cus = 0;
   if (phase2_cus == 0) return WCA_OK;
-  // mask bit i = CU i of the device's enumeration; the round-robin of mask bits over the 8 XCDs gives both partitions CUs on every XCD
-  const int words = (e->n_cu + 31) / 32;
-  std::vector<uint32_t> m1(words, 0u), m2(words, 0u);
-  for (int i = 0; i < e->n_cu; ++i) (i < phase2_cus ? m2 : m1)[i >> 5] |= 1u << (i & 31);
-  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s1, (uint32_t)words, m1.data()));
-  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s2, (uint32_t)words, m2.data()));
-  HIPCHK(hipExtStreamCreateWithCUMask(&e->part_s3, (uint32_t)words, m2.data()));
+  e->part_s1 = ns[0];
+  e->part_s2 = ns[1];
+  e->part_s3 = ns[2];
   e->saved_s2 = e->stream2;
   e->saved_s3 = e->stream3;
-  e->stream = e->part_s1;   // (wca_engine_set_stream is ignored while the partition is active: the caller's stream has no CU mask)
+  e->stream = e->part_s1;   // (wca_engine_set_stream only RECORDS the caller's stream while the partition is active: that stream has no CU mask)
   e->stream2 = e->part_s2;
   e->stream3 = e->part_s3;
   e->part_cus = phase2_cus;
@@ -1660,6 +1729,7 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
   const wca_model_dims& D = e->dims;
   const int d = D.n_audio_state, dt = D.n_text_state;
   int rc = 1;
+  size_t n_inexact = 0;   // elements of this tensor that its f16 storage rounded (put_f16 / put_conv)
 #define WANTN(cnt) \
   if (n != (size_t)(cnt)) return fail(WCA_ERR_INVALID, "weight %s: expected %zu elements, got %zu", name_c, (size_t)(cnt), n)
   if (name == "mel_filters") {
@@ -1685,13 +1755,13 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     rc = WCA_OK;
   } else if (name == "encoder.conv1.weight") {
     WANTN((size_t)d * D.n_mels * 3);
-    rc = put_conv(e->conv1_w, p, dtype, d, D.n_mels, e->k1pad);
+    rc = put_conv(e->conv1_w, p, dtype, d, D.n_mels, e->k1pad, &n_inexact);
   } else if (name == "encoder.conv1.bias") {
     WANTN(d);
     rc = put_f32(e->conv1_b, p, dtype, n);
   } else if (name == "encoder.conv2.weight") {
     WANTN((size_t)d * d * 3);
-    rc = put_conv(e->conv2_w, p, dtype, d, d, 3 * d);
+    rc = put_conv(e->conv2_w, p, dtype, d, d, 3 * d, &n_inexact);
   } else if (name == "encoder.conv2.bias") {
     WANTN(d);
     rc = put_f32(e->conv2_b, p, dtype, n);
@@ -1706,7 +1776,7 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     rc = put_f32(e->lnpost_b, p, dtype, n);
   } else if (name == "decoder.token_embedding.weight") {
     WANTN((size_t)D.n_vocab * dt);
-    rc = put_f16(e->tok_emb, p, dtype, n);
+    rc = put_f16(e->tok_emb, p, dtype, n, &n_inexact);
   } else if (name == "decoder.positional_embedding") {
     WANTN((size_t)D.n_text_ctx * dt);
     rc = put_f32(e->dec_pos, p, dtype, n);
@@ -1724,12 +1794,14 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     const int li = atoi(name.substr(p0, dot - p0).c_str());
     const int nl = is_dec ? D.n_text_layer : D.n_audio_layer;
     if (li < 0 || li >= nl) return fail(WCA_ERR_INVALID, "layer index out of range in %s", name_c);
-    rc = load_block_tensor(e, is_dec ? e->dec[li] : e->enc[li], is_dec, li, name.substr(dot + 1), p, dtype, n, is_dec ? dt : d);
+    rc = load_block_tensor(e, is_dec ? e->dec[li] : e->enc[li], is_dec, li, name.substr(dot + 1), p, dtype, n, is_dec ? dt : d, &n_inexact);
   }
 #undef WANTN
   if (rc == WCA_OK) {
     e->loaded.insert(name);
     e->sw_dirty = true;
+    if (n_inexact) e->inexact[name] = n_inexact;
+    else e->inexact.erase(name);
   }
   return rc < 0 ? rc : WCA_OK;  // unknown names (e.g. alignment_heads) are ignored
 }
@@ -1756,6 +1828,25 @@ int wca_finalize_weights(wca_engine* e) {
   for (const auto& nm : need)
     if (!e->loaded.count(nm)) return fail(WCA_ERR_STATE, "missing weight %s", nm.c_str());
   e->finalized = true;
+  return WCA_OK;
+}
+
+int wca_weights_inexact(wca_engine* e, long long* n_tensors_out, long long* n_values_out, char* first_name_out, int first_name_cap) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  long long tot = 0;
+  for (const auto& kv : e->inexact) tot += (long long)kv.second;
+  if (n_tensors_out) *n_tensors_out = (long long)e->inexact.size();
+  if (n_values_out) *n_values_out = tot;
+  if (first_name_out && first_name_cap > 0) {
+    const std::string f = e->inexact.empty() ? std::string() : e->inexact.begin()->first;
+    snprintf(first_name_out, (size_t)first_name_cap, "%s", f.c_str());
+  }
+  return WCA_OK;
+}
+
+int wca_set_allow_rounded_weights(wca_engine* e, int on) {
+  if (!e) return fail(WCA_ERR_INVALID, "null engine");
+  e->allow_rounded = on != 0;
   return WCA_OK;
 }
 
@@ -2426,7 +2517,7 @@ int wca_greedy_decode(wca_engine* e, const float* mel_dev, const float* pcm_dev,
     HIPCHK(hipStreamWaitEvent(e->stream3, e->ev_fork, 0));
   }
   int steps = 0;
-  const bool dbg_host = std::getenv("WCA_DEC_DEBUG") != nullptr;
+  static const bool dbg_host = std::getenv("WCA_DEC_DEBUG") != nullptr;   // (read once)
   double host_us = 0.0;
   for (int t = 0; t < T_max - 1; ++t) {
     const bool sample = (t >= n_initial - 1);
@@ -2723,6 +2814,7 @@ int wca_test_gemm_pairs(wca_engine* e, const void* a2, const void* w, const floa
     g.c_lo = N;
   }
   g.force_tile = (out_mode >> 8) & 0xfff;
+  g.dephase = ((out_mode >> 20) & 0xff) * 1024;   // (experiment: start the persistent workgroups up to this many cycles apart)
   g.site = 1;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
@@ -2845,6 +2937,7 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, 
   g.dbg = dbg_dev;
   g.dbg_wrap_m = wrap_m;
   g.dbg_wrap_n = wrap_n;
+  g.dbg_wrap_kind = (out_mode >> 20) & 3;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }
@@ -2853,8 +2946,27 @@ int wca_test_attention_stamped(wca_engine* e, const void* q, const void* k, cons
                                unsigned long long* dbg_dev);
 
 int wca_test_set_attn_split_drop(int mask) {
-  if (mask != 0 && mask != 1 && mask != 2 && mask != 3 && mask != 4 && mask != 8 && mask != 12 && mask != 15) return fail(WCA_ERR_INVALID, "attention pass mask %d is not instantiated", mask);
-  set_attention_split_drop(mask);
+  if (mask != 0 && mask != 1 && mask != 2 && mask != 3 && mask != 4 && mask != 8 && mask != 9 && mask != 12 && mask != 15)
+    return fail(WCA_ERR_INVALID, "attention pass mask %d is not instantiated", mask);
+  set_debug_switch("attn_split_drop", mask);
+  return WCA_OK;
+}
+
+int wca_test_set_switch(const char* name, int value) {
+  if (!name) return fail(WCA_ERR_INVALID, "null argument");
+  if (set_debug_switch(name, value) != 0) return fail(WCA_ERR_INVALID, "unknown switch %s", name);
+  return WCA_OK;
+}
+
+int wca_test_last_scores(wca_engine* e, int batch, float* scores_host) {
+  if (!e || !scores_host) return fail(WCA_ERR_INVALID, "null argument");
+  if (e->enq_count != e->fetch_count) return fail(WCA_ERR_STATE, "fetch the batches in flight first");
+  HIPCHK(hipSetDevice(e->device));
+  const size_t n = (size_t)batch * e->dims.n_text_layer * e->dims.n_text_head;
+  if (batch < 1 || e->scores.bytes < n * sizeof(float)) return fail(WCA_ERR_INVALID, "no head scores of a batch of %d are held", batch);
+  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->stream2));
+  HIPCHK(hipMemcpy(scores_host, e->scores.p, n * sizeof(float), hipMemcpyDeviceToHost));
   return WCA_OK;
 }
 

@@ -547,10 +547,6 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     const int rows = (ntm - st * SM) < SM ? (ntm - st * SM) : SM;  // the last supertile may be short
     tn = r / rows;
     tm = st * SM + (r - tn * rows);
-    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15) {   // (15: the diagnostic build without the wrap)   // diagnostic builds: every workgroup walks the same few panels (operands L2-resident; outputs collide)
-      tm %= a.dbg_wrap_m;
-      tn %= a.dbg_wrap_n;
-    }
   };
   // OUT_MODE 3 (LayerNorm in the epilogue): the N/256 workgroups that hold one 256-row panel wait for each other in the
   // epilogue, so a panel's tiles must be worked on AT THE SAME TIME: round r of the 32 workgroups that share an XCD label
@@ -576,9 +572,35 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   } else {
     tile_of(id, tm_, tn_);
   }
+  // diagnostic builds (STAMP != 0): tile coordinates taken modulo (dbg_wrap_m, dbg_wrap_n) -- for the OPERAND addresses (every workgroup then
+  // walks the same few panels: an L2-resident footprint), for the OUTPUT addresses (stores collide in a few tiles), or both (dbg_wrap_kind 1 / 2 / 0;
+  // dbg_wrap_m == 15: the diagnostic instantiation without any wrap)
+  auto wrap_opnd = [&](int& tm, int& tn) {
+    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && a.dbg_wrap_kind != 2) {
+      tm %= a.dbg_wrap_m;
+      tn %= a.dbg_wrap_n;
+    }
+  };
+  auto wrap_out = [&](int& tm, int& tn) {
+    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && a.dbg_wrap_kind != 1) {
+      tm %= a.dbg_wrap_m;
+      tn %= a.dbg_wrap_n;
+    }
+  };
+  int tma_ = tm_, tna_ = tn_;
+  wrap_opnd(tma_, tna_);
+  wrap_out(tm_, tn_);
   int m0 = tm_ * 256, n0 = tn_ * 256;
-  unsigned ta = (unsigned)m0 * a.lda * 2u, tw = (unsigned)n0 * a.ldw * 2u;
+  unsigned ta = (unsigned)(tma_ * 256) * a.lda * 2u, tw = (unsigned)(tna_ * 256) * a.ldw * 2u;
 
+  // De-phasing of the persistent workgroups (a.dephase > 0, cycles): the 32 workgroups of an XCD label start up to a.dephase cycles apart, so
+  // that their tile epilogues -- 256 KiB of stores per workgroup, issued by all 256 CUs at the same moment when they run in phase -- spread
+  // over the K loops of the others.
+  if (a.dephase > 0 && G < nwg) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long wait = (unsigned long long)a.dephase * (unsigned)((blockIdx.x >> 3) & 31) / 32u;
+    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+  }
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -629,8 +651,11 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       idn = has_next ? xcd_remap(vn, nwg) : id;
       tile_of(idn, tmn_, tnn_);
     }
+    int tman_ = tmn_, tnan_ = tnn_;
+    wrap_opnd(tman_, tnan_);
+    wrap_out(tmn_, tnn_);
     const int m0n = tmn_ * 256, n0n = tnn_ * 256;
-    const unsigned tan = (unsigned)m0n * a.lda * 2u, twn = (unsigned)n0n * a.ldw * 2u;
+    const unsigned tan = (unsigned)(tman_ * 256) * a.lda * 2u, twn = (unsigned)(tnan_ * 256) * a.ldw * 2u;
     // one K step; PAR >= 0: the step's parity (= its A ring slot) is a compile-time constant (SPLITW: even = first use of a W tile)
     auto kstep = [&](auto par_c, const int kt) {
       constexpr int PAR = decltype(par_c)::value;
@@ -936,9 +961,10 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const int nk = (splitw ? 2 : 1) * (a.K / BK);
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
       // (K <= 2048 since round 3: the K-doubled QKV / fc1 of the split mode measure -5 % / -3 % with the supertile order, same-box A/B)
+      if (a.dephase == 0) a.dephase = debug_switch(DBG_GEMM_DEPHASE);   // (experiment: cycles)
       if (a.supertile <= 0) {
-        const char* ev = std::getenv("WCA_GEMM_SUPERTILE");   // (tile-order experiments)
-        a.supertile = ev ? atoi(ev) : (((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1);
+        const int sw = debug_switch(DBG_GEMM_SUPERTILE);   // (tile-order experiments)
+        a.supertile = sw > 0 ? sw : (((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1);
       }
     }
   } else {

@@ -7,6 +7,12 @@ namespace wca {
 
 typedef _Float16 half_t;
 
+// ---------------------------------------------------------------- A/B and test switches (debug_switch.cpp; wca_test_set_switch)
+enum { DBG_ATTN_SPLIT_VARIANT = 0, DBG_ATTN_VARIANT, DBG_HEAD_STATS_GENERAL, DBG_GEMM_SUPERTILE, DBG_LN_PAIR_V4, DBG_FAIL_PRECISION_ALLOC, DBG_GEMM_DEPHASE,
+       DBG_ATTN_SPLIT_DROP, DBG_SWITCH_COUNT };
+int debug_switch(int id);                            // current value (its environment variable, if any, read once as the initial value)
+int set_debug_switch(const char* name, int value);   // 0, or -1 for an unknown name
+
 // ---------------------------------------------------------------- GEMM (gemm.hip)
 // C[m][n] = epilogue( sum_k A[m][k] * W[n][k] ),  A/W f16, fp32 accumulate on MFMA.
 // Rows of A and C may be "batch strided": logical row m = b * rows_per_batch + t lives at
@@ -38,6 +44,8 @@ struct GemmArgs {
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
+  int dephase;             // persistent 256x256 kernel: > 0 = the workgroups of an XCD label start up to this many cycles apart (experiment)
+  int dbg_wrap_kind;       // diagnostic builds only: 0 wrap operand AND output addresses, 1 operands only, 2 outputs only
   int dbg_wrap_m, dbg_wrap_n; // diagnostic builds only: tile coordinates taken modulo these (an L2-resident operand footprint; outputs collide)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
   // out_mode 3 only (the residual GEMMs of a transformer block, N = n_state <= 2048, a multiple of 256):
@@ -103,9 +111,8 @@ struct AttnArgs {
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s);  // attention_split.hip (launch_attention forwards a.split != 0 here)
-// diagnostic (process-wide, 0 in the product): leave single passes out of the encoder's three-pass attention -- bit 0 K_lo Q_hi, bit 1 K_hi Q_lo,
-// bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 12, 15 are instantiated
-void set_attention_split_drop(int mask);
+// (diagnostic switch DBG_ATTN_SPLIT_DROP, 0 in the product: leaves single passes out of the encoder's three-pass attention -- bit 0 K_lo Q_hi,
+// bit 1 K_hi Q_lo, bit 2 V_lo P_hi, bit 3 V_hi P_lo; masks 0, 1, 2, 3, 4, 8, 9, 12, 15 are instantiated)
 
 // ---------------------------------------------------------------- small ops (elementwise.hip)
 // ld_out: elements between output rows (0 = d). lo_off != 0: split output, hi = f16(y) at out, lo = f16(y - hi) at out + lo_off

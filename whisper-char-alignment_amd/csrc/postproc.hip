@@ -715,8 +715,8 @@ hipError_t launch_head_stats(const HeadStatsArgs& a, hipStream_t s) {
   const int Fmax = a.n_frames_max;
   dim3 grid(a.LH, a.B), block(256);
   const int w = a.medfilt_width;
-  // the instruction-lean kernel (same bits) for logits input and the unrolled filter widths; WCA_HEAD_STATS_GENERAL=1 keeps the general one (A/B, tests)
-  if (!a.input_is_weights && w <= 9 && !std::getenv("WCA_HEAD_STATS_GENERAL")) {
+  // the instruction-lean kernel (same bits) for logits input and the unrolled filter widths; the switch head_stats_general keeps the general one (A/B, tests)
+  if (!a.input_is_weights && w <= 9 && !debug_switch(DBG_HEAD_STATS_GENERAL)) {
 #define WCA_HSF(NPL, W)                                                                                   \
   do {                                                                                                    \
     const size_t shm = sizeof(float) * (4 * (size_t)(64 * NPL + 2 * HALO) + 8 * (size_t)Fmax + 16);      \

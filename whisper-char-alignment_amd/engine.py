@@ -131,7 +131,7 @@ def default_engine(device_index=0, need_weights=False):
         raise RuntimeError("no WhisperAMD engine with weights exists on cuda:%d" % device_index)
     if device_index not in _utility:
         _utility[device_index] = WhisperAMD(ModelDimensions(80, 1500, 128, 2, 1, 51865, 448, 128, 2, 1),
-                                            device="cuda:%d" % device_index, max_batch=1, _register=False)
+                                            device="cuda:%d" % device_index, max_batch=1, _register=False, precision="f16")   # (runs no forward)
     return _utility[device_index]
 
 
@@ -140,7 +140,12 @@ def _ptr(t):
 
 
 class WhisperAMD:
-    def __init__(self, dims, device="cuda:0", max_batch=8, _register=True):
+    def __init__(self, dims, device="cuda:0", max_batch=8, _register=True, precision="reference"):
+        """precision: 'reference' (default since round 5, like wca_engine_create): the CONTRACT mode -- the reference's fp32 forward
+        (/root/reference/timing.py:58) to fp32 summation noise; 'f16': the fast single-f16-operand mode (98.5 % of the word boundaries
+        within one frame on the parity legs) as an explicit opt-in. set_precision() switches later."""
+        if precision not in ("reference", "split", "f16"):
+            raise ValueError("precision must be 'reference' (= 'split') or 'f16'")
         if not torch.cuda.is_available():
             raise RuntimeError("WhisperAMD needs an AMD GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self._lib = _lib.load()
@@ -150,7 +155,7 @@ class WhisperAMD:
         self._h = C.c_void_p(0)
         cd = _lib.ModelDims(**asdict(dims))
         index = self.device.index if self.device.index is not None else 0
-        _lib.check(self._lib.wca_engine_create(C.byref(cd), index, self.max_batch, C.byref(self._h)))
+        _lib.check(self._lib.wca_engine_create_ex(C.byref(cd), index, self.max_batch, 0 if precision == "f16" else 1, C.byref(self._h)))
         self._stream_bound = None
         self._finalized = False
         # whisper.model.Whisper default: every head of the upper half of the decoder layers; whisper.load_model(name)
@@ -231,38 +236,68 @@ class WhisperAMD:
         shape = (C.c_int64 * max(arr.ndim, 1))(*(arr.shape if arr.ndim else (1,)))
         _lib.check(self._lib.wca_load_weight(self._h, name.encode(), arr.ctypes.data_as(C.c_void_p), dt, shape, max(arr.ndim, 1)))
 
-    def load_state_dict(self, sd):
-        """sd: openai-whisper naming (encoder.blocks.0.attn.query.weight ...), torch tensors or numpy arrays."""
+    def load_state_dict(self, sd, allow_rounded_weights=False):
+        """sd: openai-whisper naming (encoder.blocks.0.attn.query.weight ...), torch tensors or numpy arrays.
+        Weight matrices are stored f16 (every openai checkpoint is f16 at rest; whisper.load_model upcasts those values,
+        /root/reference/infer_ali.py:36-37). An fp32 state dict whose values are NOT f16-representable would be rounded by that: in the
+        contract mode this raises (never a silently narrower model) unless allow_rounded_weights=True; the f16 mode always loads.
+        `weights_inexact` reports what was rounded."""
+        _lib.check(self._lib.wca_set_allow_rounded_weights(self._h, 1 if allow_rounded_weights else 0))
         for name, t in sd.items():
             self._load_one(name, t)
         _lib.check(self._lib.wca_finalize_weights(self._h))
         self._finalized = True
+        n_t, n_v, first = self.weights_inexact
+        if n_t and not allow_rounded_weights and self.precision != "f16":
+            raise ValueError("%d weight tensor(s) hold %d fp32 value(s) that are not f16-representable (first: %s): the contract precision mode "
+                             "computes the reference's fp32 forward only on weights that are exact in f16. Pass allow_rounded_weights=True to run "
+                             "on the rounded weights, or precision='f16'." % (n_t, n_v, first))
         return self
 
+    @property
+    def weights_inexact(self):
+        """(tensors, values, name of the first tensor) whose fp32 source values the f16 weight storage rounded; (0, 0, '') for f16 checkpoints."""
+        nt, nv = C.c_longlong(0), C.c_longlong(0)
+        buf = C.create_string_buffer(160)
+        _lib.check(self._lib.wca_weights_inexact(self._h, C.byref(nt), C.byref(nv), buf, 160))
+        return int(nt.value), int(nv.value), buf.value.decode()
+
     @classmethod
-    def from_checkpoint(cls, path, device="cuda:0", max_batch=8, name=None, precision="reference"):
+    def from_checkpoint(cls, path, device="cuda:0", max_batch=8, name=None, precision="reference", allow_rounded_weights=False):
         """Loads an openai-format checkpoint ({'dims':..., 'model_state_dict':...}) from a LOCAL path and, like
         whisper.load_model(name), installs the official alignment heads of `name` (inferred from the dimensions when
         they identify the model; large-v1 / large-v2 need the name). This is the drop-in's `whisper.load_model`: the model comes
-        back in the CONTRACT precision mode ('reference': the fp32 forward of timing.py:58 to fp32 summation noise), unlike a bare
-        WhisperAMD(), which starts in the f16 fast mode; precision='f16' opts out."""
+        back in the CONTRACT precision mode ('reference': the fp32 forward of timing.py:58 to fp32 summation noise), like a bare
+        WhisperAMD(); precision='f16' opts out. A checkpoint whose fp32 weights are not f16-representable raises unless
+        allow_rounded_weights=True (load_state_dict)."""
         ck = torch.load(path, map_location="cpu")
         dims = ModelDimensions(**ck["dims"])
-        m = cls(dims, device=device, max_batch=max_batch)
-        m.load_state_dict(ck["model_state_dict"])
+        m = cls(dims, device=device, max_batch=max_batch, precision=precision)
+        m.load_state_dict(ck["model_state_dict"], allow_rounded_weights=allow_rounded_weights)
         m.use_official_alignment_heads(name)
-        m.set_precision(precision)
         return m
 
     # ---- stream handling: always run on torch's current stream so torch tensors stay ordered
     def _bind_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
+        if getattr(self, "_partitioned", False):
+            # CU-partitioned engine: its masked streams are not ordered with torch's stream -- complete the caller's work first (and every
+            # entry point that returns device tensors synchronises the engine afterwards: _after_call)
+            torch.cuda.current_stream(self.device).synchronize()
         if s != self._stream_bound:
-            _lib.check(self._lib.wca_engine_set_stream(self._h, C.c_void_p(s)))
+            rc = self._lib.wca_engine_set_stream(self._h, C.c_void_p(s))
+            if rc != 1:   # WCA_STATUS_PARTITIONED: recorded only
+                _lib.check(rc)
             self._stream_bound = s
 
     def synchronize(self):
         _lib.check(self._lib.wca_engine_synchronize(self._h))
+
+    def _after_call(self):
+        """Entry points that leave their results in device tensors are ordered with torch's stream by running ON it -- except on a
+        CU-partitioned engine, whose masked streams torch knows nothing about: wait for them here."""
+        if getattr(self, "_partitioned", False):
+            self.synchronize()
 
     # ---- hot path entry points (thin wrappers; shapes documented in include/wca.h)
     def log_mel(self, pcm, n_samples=None):
@@ -280,6 +315,7 @@ class WhisperAMD:
         for b0 in range(0, B, self.max_batch):
             b1 = min(B, b0 + self.max_batch)
             _lib.check(self._lib.wca_log_mel(self._h, _ptr(p[b0:b1]), n, _lib.i32_array(ns[b0:b1]), b1 - b0, _ptr(out[b0:b1])))
+        self._after_call()
         return out[0] if single else out
 
     def get_attentions(self, mel, tokens, max_frames, medfilt_width=7, qk_scale=1.0, n_tok=None, want_logits=True):
@@ -298,6 +334,7 @@ class WhisperAMD:
         nt = _lib.i32_array(n_tok) if n_tok is not None else None
         _lib.check(self._lib.wca_get_attentions(self._h, _ptr(mel), _ptr(tokens), B, n, nt, _lib.i32_array(mf),
                                                 int(medfilt_width), float(qk_scale), _ptr(weights), _ptr(logits)))
+        self._after_call()
         return weights, logits
 
     def encode(self, mel):
@@ -307,6 +344,7 @@ class WhisperAMD:
         out = torch.empty(B, 1500, self.dims.n_audio_state, device=self.device, dtype=torch.float32)
         self._bind_stream()
         _lib.check(self._lib.wca_test_encoder(self._h, _ptr(mel), B, _ptr(out)))
+        self._after_call()
         return out
 
     def make_opts(self, aggregation="mean", topk=-1, w_colnorm=1.0, w_rownorm=1.0, w_coverage=0.0, sot_len=3,
@@ -503,6 +541,8 @@ class WhisperAMD:
         phase 1 on the rest; 0 lifts it. Inputs must be complete (synchronised) before the engine is called while it is active."""
         torch.cuda.synchronize()
         _lib.check(self._lib.wca_set_cu_partition(self._h, int(phase2_cus)))
+        self._partitioned = int(phase2_cus) > 0
+        self._stream_bound = None   # re-bind torch's current stream at the next call (ADVICE r4: after a lift the engine must not stay on a private stream)
 
     def set_decode_mode(self, fused=True, streams=1):
         """Few-row decoder GEMMs fused with LayerNorm / KV append / split-K (default) or separate launches; greedy decode as
