@@ -259,6 +259,11 @@ def test_flac_rfc9639_example_known_answer():
     bad[-4] ^= 0x10  # corrupt one payload bit: the frame CRC-16 must catch it
     with pytest.raises(ValueError):
         audio._read_flac(bytes(bad))
+    huge = bytearray(b)
+    huge[21] |= 0x0f  # STREAMINFO total_samples = 2^35 + ...: must be rejected after COUNTING the stream, not by allocating 8 x 2^35 floats
+    huge[22:26] = b"\xff\xff\xff\xff"
+    with pytest.raises(ValueError):
+        audio._read_flac(bytes(huge))
 
 
 def test_flac_decoder_round_trip(tmp_path):

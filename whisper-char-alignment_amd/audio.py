@@ -169,7 +169,9 @@ def _read_flac(buf):
         raise ValueError("not a FLAC stream")
     n = C.c_int64(0)
     n_total = total.value
-    if n_total <= 0:  # STREAMINFO without a sample count: count first
+    if n_total <= 0 or n_total > len(buf) * 8192:
+        # STREAMINFO without a sample count, or with one no stream of this size can hold (a 10-byte CONSTANT frame codes at most 65 536
+        # samples): a corrupt or hostile header must not size the allocation below -- count first
         if lib.wca_flac_decode(src, len(buf), None, 0, C.byref(n)) != 0:
             raise ValueError("corrupt or unsupported FLAC stream")
         n_total = n.value

@@ -11,6 +11,15 @@
 
 #include "../../include/wca.h"
 
+// Fuzzing builds only (tools/flac_fuzz.cpp, tests/test_flac_fuzz.py: g++ -fsanitize=address,undefined on the CPU): with
+// -DWCA_FLAC_FUZZ_SKIP_CRC the frame CRCs are computed but not enforced, so that mutated streams reach the subframe / residual
+// decoders instead of being rejected at the checksum. The product build (build.py) never defines it.
+#ifdef WCA_FLAC_FUZZ_SKIP_CRC
+#define WCA_FLAC_CRC_MISMATCH(a, b) (((a) != (b)) && false)
+#else
+#define WCA_FLAC_CRC_MISMATCH(a, b) ((a) != (b))
+#endif
+
 namespace {
 
 struct BitReader {
@@ -271,7 +280,7 @@ int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capa
     if (bps != si.bps) return WCA_ERR_INVALID;  // a mid-stream change of sample size is not supported
     const size_t hdr_len = br.byte_pos();
     const uint8_t want8 = (uint8_t)br.read(8);
-    if (br.bad || crc8(buf + pos, hdr_len) != want8) return WCA_ERR_INVALID;
+    if (br.bad || WCA_FLAC_CRC_MISMATCH(crc8(buf + pos, hdr_len), want8)) return WCA_ERR_INVALID;
     int nch;
     if (ch_code < 8) nch = ch_code + 1;
     else if (ch_code <= 10) nch = 2;
@@ -286,17 +295,19 @@ int wca_flac_decode(const uint8_t* buf, int64_t nbytes, float* out, int64_t capa
     br.align_byte();
     const size_t body_len = br.byte_pos();
     const uint16_t want16 = (uint16_t)br.read(16);
-    if (br.bad || crc16(buf + pos, body_len) != want16) return WCA_ERR_INVALID;
+    if (br.bad || WCA_FLAC_CRC_MISMATCH(crc16(buf + pos, body_len), want16)) return WCA_ERR_INVALID;
+    // inter-channel decorrelation in wrapping / 64-bit arithmetic: a crafted (CRC-valid) stream can carry side values that overflow int32
+    // (found by the sanitizer fuzz build, tests/test_flac_fuzz.py; valid streams never get there)
     if (ch_code == 8) {
-      for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
+      for (int i = 0; i < blocksize; ++i) ch[1][i] = (int32_t)((uint32_t)ch[0][i] - (uint32_t)ch[1][i]);
     } else if (ch_code == 9) {
-      for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[0][i] + ch[1][i];
+      for (int i = 0; i < blocksize; ++i) ch[0][i] = (int32_t)((uint32_t)ch[0][i] + (uint32_t)ch[1][i]);
     } else if (ch_code == 10) {
       for (int i = 0; i < blocksize; ++i) {
-        const int32_t side = ch[1][i];
-        const int32_t mid = (int32_t)(((uint32_t)ch[0][i] << 1) | ((uint32_t)side & 1));
-        ch[0][i] = (mid + side) >> 1;
-        ch[1][i] = (mid - side) >> 1;
+        const int64_t side = ch[1][i];
+        const int64_t mid = (int64_t)(((uint64_t)(int64_t)ch[0][i] << 1) | ((uint64_t)side & 1));
+        ch[0][i] = (int32_t)((mid + side) >> 1);
+        ch[1][i] = (int32_t)((mid - side) >> 1);
       }
     }
     int64_t take = blocksize;
