@@ -301,7 +301,6 @@ int wca_test_gemm(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, c
  * w = the PLAIN [N][K] matrix, K the algorithmic depth. out_mode as above (0, 1, 2, 4; >> 8: 0 auto, 257, 258).
  * WCA_ERR_INVALID where that kernel does not apply (fewer than 192 256 x 256 tiles, K % 128 != 0): the engine then multiplies
  * the K-doubled operands through wca_test_gemm's path. */
-/* (wca_test_gemm_pairs: out_mode bits 20-27 = the persistent workgroups' start spread in units of 1024 cycles, an experiment) */
 int wca_test_gemm_pairs(wca_engine* e, const void* a2_f16_dev, const void* w_f16_dev, const float* bias_dev, void* c_dev, int M,
                         int N, int K, int gelu, int out_mode);
 /* x (f32 [M][N], read-modify-write) += A W^T + bias; xn (f16 [M][N]) = LayerNorm(x; gamma, beta, eps 1e-5): the residual
@@ -331,7 +330,7 @@ int wca_test_set_attn_split_drop(int mask);
 /* A/B and test switches of the library, process-wide (csrc/debug_switch.cpp; every default is the shipped choice and the product never calls
  * this): "attn_split_variant" (1: pair attention on the 16x16x32 kernel everywhere), "attn_variant" (f16 attention: 1 / 3), "head_stats_general"
  * (1: the general head-statistics kernel), "gemm_supertile" (m-panels per supertile), "ln_pair_v4", "fail_precision_alloc" (1: the next
- * precision switch fails its allocation: the roll-back test), "gemm_dephase" (cycles), "attn_split_drop". The environment variable of the same
+ * precision switch fails its allocation: the roll-back test), "attn_split_drop". The environment variable of the same
  * meaning (WCA_ATTN_SPLIT_VARIANT, ...) is read ONCE, as the switch's initial value, never per launch. */
 int wca_test_set_switch(const char* name, int value);
 /* the [batch][n_text_layer * n_text_head] head selection scores (timing.py:13-43) of the LAST fused batch, after it was fetched (no batch in

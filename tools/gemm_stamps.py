@@ -89,13 +89,4 @@ for name, n, k, mode, pairs in SHAPES:
         fl = flags | (wr << 12) | (wr << 16) | (kind << 20)
         t[label] = min(timeit(lambda: chk(lib.wca_test_gemm_stamped(eng._h, vp(A), vp(w), vp(out), M, n, k, fl, None))) for _ in range(3))
     print("%s timing: " % tag + "  ".join("%s %.3f ms" % kv for kv in t.items()), flush=True)
-    if pairs:   # start spread of the persistent workgroups (product kernel): 0 / 1/8 / 1/4 / 1/2 / 1 tile period (~ nk x 3 400 cycles)
-        period = nk * 3400
-        td = {}
-        for frac in (0.0, 0.125, 0.25, 0.5, 1.0):
-            units = min(255, int(round(period * frac / 1024)))
-            for _ in range(2):
-                v = min(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om | (units << 20)))) for _ in range(3))
-                td[frac] = min(td.get(frac, 1e9), v)
-        print("%s start spread (fraction of a tile period): " % tag + "  ".join("%.3f: %.3f ms" % kv for kv in td.items()), flush=True)
     del a, hi, A, w, out

@@ -24,7 +24,6 @@ Sw g_sw[DBG_SWITCH_COUNT] = {
     {"gemm_supertile", "WCA_GEMM_SUPERTILE", {0}, {0}},             // > 0: m-panels per supertile of the persistent GEMM's tile order
     {"ln_pair_v4", "WCA_LN_PAIR_V4", {0}, {0}},                     // 1: the four-wide pair LayerNorm
     {"fail_precision_alloc", "WCA_TEST_FAIL_PRECISION_ALLOC", {0}, {0}},  // 1: inject an allocation failure into wca_set_precision_sites
-    {"gemm_dephase", "WCA_GEMM_DEPHASE", {0}, {0}},                 // > 0: cycles over which the persistent GEMM's workgroups are started apart
     {"attn_split_drop", nullptr, {0}, {0}},                         // pass mask of the encoder's pair attention (wca_test_set_attn_split_drop)
 };
 }  // namespace

@@ -2814,7 +2814,6 @@ int wca_test_gemm_pairs(wca_engine* e, const void* a2, const void* w, const floa
     g.c_lo = N;
   }
   g.force_tile = (out_mode >> 8) & 0xfff;
-  g.dephase = ((out_mode >> 20) & 0xff) * 1024;   // (experiment: start the persistent workgroups up to this many cycles apart)
   g.site = 1;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;

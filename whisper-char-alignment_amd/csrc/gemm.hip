@@ -593,14 +593,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   int m0 = tm_ * 256, n0 = tn_ * 256;
   unsigned ta = (unsigned)(tma_ * 256) * a.lda * 2u, tw = (unsigned)(tna_ * 256) * a.ldw * 2u;
 
-  // De-phasing of the persistent workgroups (a.dephase > 0, cycles): the 32 workgroups of an XCD label start up to a.dephase cycles apart, so
-  // that their tile epilogues -- 256 KiB of stores per workgroup, issued by all 256 CUs at the same moment when they run in phase -- spread
-  // over the K loops of the others.
-  if (a.dephase > 0 && G < nwg) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-    const unsigned long long wait = (unsigned long long)a.dephase * (unsigned)((blockIdx.x >> 3) & 31) / 32u;
-    while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-  }
+  // (Round-5 experiment, removed: starting the 32 workgroups of an XCD label up to 1/8 ... 1 tile period apart, so that the tile epilogues --
+  //  256 KiB of stores per workgroup, issued by all 256 CUs at the same moment when they run in phase -- spread over the others' K loops:
+  //  pair fc1 1.543 / 1.543 / 1.537 / 1.551 / 1.553 ms at 0 / 1/8 / 1/4 / 1/2 / 1 period, QKV 1.125 ... 1.132, fc2 1.357 ... 1.445: nothing, then worse.)
   f32x4 acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -961,7 +956,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       const int nk = (splitw ? 2 : 1) * (a.K / BK);
       if (a.force_tile != 258 && nk >= 2 && (nk & 1) == 0 && tiles256 > n_cu) grid = dim3((unsigned)n_cu);
       // (K <= 2048 since round 3: the K-doubled QKV / fc1 of the split mode measure -5 % / -3 % with the supertile order, same-box A/B)
-      if (a.dephase == 0) a.dephase = debug_switch(DBG_GEMM_DEPHASE);   // (experiment: cycles)
       if (a.supertile <= 0) {
         const int sw = debug_switch(DBG_GEMM_SUPERTILE);   // (tile-order experiments)
         a.supertile = sw > 0 ? sw : (((splitw ? 2 : 1) * a.K <= 2048 && (a.N + 255) / 256 <= 32) ? 8 : 1);

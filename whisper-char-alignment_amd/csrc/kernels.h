@@ -8,7 +8,7 @@ namespace wca {
 typedef _Float16 half_t;
 
 // ---------------------------------------------------------------- A/B and test switches (debug_switch.cpp; wca_test_set_switch)
-enum { DBG_ATTN_SPLIT_VARIANT = 0, DBG_ATTN_VARIANT, DBG_HEAD_STATS_GENERAL, DBG_GEMM_SUPERTILE, DBG_LN_PAIR_V4, DBG_FAIL_PRECISION_ALLOC, DBG_GEMM_DEPHASE,
+enum { DBG_ATTN_SPLIT_VARIANT = 0, DBG_ATTN_VARIANT, DBG_HEAD_STATS_GENERAL, DBG_GEMM_SUPERTILE, DBG_LN_PAIR_V4, DBG_FAIL_PRECISION_ALLOC,
        DBG_ATTN_SPLIT_DROP, DBG_SWITCH_COUNT };
 int debug_switch(int id);                            // current value (its environment variable, if any, read once as the initial value)
 int set_debug_switch(const char* name, int value);   // 0, or -1 for an unknown name
@@ -44,7 +44,6 @@ struct GemmArgs {
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
-  int dephase;             // persistent 256x256 kernel: > 0 = the workgroups of an XCD label start up to this many cycles apart (experiment)
   int dbg_wrap_kind;       // diagnostic builds only: 0 wrap operand AND output addresses, 1 operands only, 2 outputs only
   int dbg_wrap_m, dbg_wrap_n; // diagnostic builds only: tile coordinates taken modulo these (an L2-resident operand footprint; outputs collide)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
