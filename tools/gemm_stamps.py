@@ -43,7 +43,10 @@ M = B * 1500
 SHAPES = [("fc1", 4096, 1024, 4 | 256, True), ("qkv", 3072, 1024, 4, True), ("fc2", 1024, 4096, 2, True), ("out", 1024, 1024, 2, True),
           ("fc1", 4096, 1024, 0 | 256, False), ("qkv", 3072, 1024, 0, False), ("fc2", 1024, 4096, 2, False)]
 # (the stamp buffer holds 48 K steps per wave: the K = 4096 shapes' step stamps overlap the tile stamps -- read their timings, not their stamp rows)
+only = sys.argv[3] if len(sys.argv) > 3 else ""
 for name, n, k, mode, pairs in SHAPES:
+    if only and (name != only.split(":")[-1] or (only.startswith("pair:") and not pairs) or (only.startswith("f16:") and pairs)):
+        continue
     a = torch.randn(M, k, device="cuda") * 0.5
     hi = a.half()
     A = torch.cat([hi, (a - hi.float()).half()], dim=1).contiguous() if pairs else hi
@@ -78,6 +81,8 @@ for name, n, k, mode, pairs in SHAPES:
               " || tile: epilogue %6.0f, period %7.0f cycles (K loop %d steps)" %
               (tag, "wrapped 2x2" if wrap == 2 else "real walk  ", len(rows), *r.mean(axis=0)[:6], r[:, 6].mean(), r[:, 7].mean(), nk), flush=True)
         print("      per-wave step means: " + " ".join("%.0f" % x for x in r[:, 5]), flush=True)
+        if len(rows) >= 8:   # workgroup 0, wave by wave (waves w and w + 4 share a SIMD): half0 / wait / barrier / half1
+            print("      workgroup 0 by wave [half0 wait barrier half1]: " + "  ".join("w%d %.0f %.0f %.0f %.0f" % (i, *r[i, :4]) for i in range(8)), flush=True)
     # plain timings (no stamps): product kernel, diagnostic instantiation without wrap, wrapped 2x2, wrapped 1x1
     t = {}
     bias = None
@@ -85,7 +90,8 @@ for name, n, k, mode, pairs in SHAPES:
         t["product"] = min(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om))) for _ in range(3))
     else:
         t["product"] = min(timeit(lambda: chk(lib.wca_test_gemm(eng._h, vp(A), vp(w), vp(bias), vp(out), M, n, k, (mode >> 8) & 1, om))) for _ in range(3))
-    for label, wr, kind in (("diag no-wrap", 15, 0), ("wrapped 2x2", 2, 0), ("operands wrapped 2x2, real outputs", 2, 1), ("real operands, outputs wrapped 2x2", 2, 2), ("wrapped 1x1", 1, 0)):
+    for label, wr, kind in (("diag no-wrap", 15, 0), ("wrapped 2x2", 2, 0), ("operands wrapped 2x2, real outputs", 2, 1), ("real operands, outputs wrapped 2x2", 2, 2), ("wrapped 1x1", 1, 0),
+                            ("real walk, packed DMA sources", 15, 4), ("wrapped 2x2, packed DMA sources", 2, 4)):
         fl = flags | (wr << 12) | (wr << 16) | (kind << 20)
         t[label] = min(timeit(lambda: chk(lib.wca_test_gemm_stamped(eng._h, vp(A), vp(w), vp(out), M, n, k, fl, None))) for _ in range(3))
     print("%s timing: " % tag + "  ".join("%s %.3f ms" % kv for kv in t.items()), flush=True)

@@ -473,9 +473,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   const int nt_r = rho >> 4, i_r = rho & 15;
   const int wsrc_row = (OUT_MODE == 0 || OUT_MODE == 3 || OUT_MODE == 4) ? ((nt_r >> 1) * 32 + (i_r >> 2) * 8 + (nt_r & 1) * 4 + (i_r & 3)) : rho;
   // per-lane byte offsets inside a tile (tile base and K offset are wave-uniform and added per request)
-  const unsigned va = (unsigned)(rho * a.lda + c0 * 8) * 2u;
-  const unsigned vw = (unsigned)(wsrc_row * a.ldw + c0 * 8) * 2u;
-  const unsigned sa64 = 64u * a.lda * 2u, sw64 = 64u * a.ldw * 2u;
+  // diagnostic builds, dbg_wrap_kind bit 2 ("packed sources", timing only -- the products are garbage): every DMA piece reads 1 KiB of CONTIGUOUS
+  // global memory (as if the operands were stored tile-packed, [panel][K step][256 rows][64]) instead of 8 rows x 128 bytes lda apart; same bytes per
+  // panel, same panels. Answers whether the row-strided source pattern costs anything in the L2 -> LDS path.
+  const bool packed_src = STAMP != 0 && (a.dbg_wrap_kind & 4) != 0;
+  const unsigned va = packed_src ? (unsigned)(rho * 64 + c0 * 8) * 2u : (unsigned)(rho * a.lda + c0 * 8) * 2u;
+  const unsigned vw = packed_src ? (unsigned)(wsrc_row * 64 + c0 * 8) * 2u : (unsigned)(wsrc_row * a.ldw + c0 * 8) * 2u;
+  const unsigned sa64 = packed_src ? 64u * 64u * 2u : 64u * a.lda * 2u, sw64 = packed_src ? 64u * 64u * 2u : 64u * a.ldw * 2u;
 
   // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each.
   // ta / tw: byte offset of (tile row 0, K offset) in A / W.
@@ -517,8 +521,14 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 
   const int nk = SPLITW ? 2 * (a.K / BK) : a.K / BK;   // K steps of one tile
   // byte offset of K step s inside an A row / a W row
-  auto a_koff = [&](int s_) -> unsigned { return SPLITW ? (unsigned)(((s_ & 1) * (int)a.a_lo + (s_ >> 1) * BK) * 2) : (unsigned)(s_ * (BK * 2)); };
-  auto w_koff = [&](int s_) -> unsigned { return SPLITW ? (unsigned)((s_ >> 1) * (BK * 2)) : (unsigned)(s_ * (BK * 2)); };
+  auto a_koff = [&](int s_) -> unsigned {
+    if (packed_src) return (unsigned)s_ * (256u * 64u * 2u);   // (K step s of a panel: its own 32 KiB)
+    return SPLITW ? (unsigned)(((s_ & 1) * (int)a.a_lo + (s_ >> 1) * BK) * 2) : (unsigned)(s_ * (BK * 2));
+  };
+  auto w_koff = [&](int s_) -> unsigned {
+    if (packed_src) return (unsigned)(SPLITW ? (s_ >> 1) : s_) * (256u * 64u * 2u);
+    return SPLITW ? (unsigned)((s_ >> 1) * (BK * 2)) : (unsigned)(s_ * (BK * 2));
+  };
   // (A/B experiments that did NOT pay on MI355X and were removed: giving the two wave groups different
   //  fetch/MFMA orders or different DMA-issue windows to break SIMD-partner lockstep; a software L2 prefetch
   //  two tiles ahead of the DMA; a 4- and 5-slot ring of K=32 tiles with the DMA 3-4 tiles ahead (-5 %);
@@ -576,13 +586,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // walks the same few panels: an L2-resident footprint), for the OUTPUT addresses (stores collide in a few tiles), or both (dbg_wrap_kind 1 / 2 / 0;
   // dbg_wrap_m == 15: the diagnostic instantiation without any wrap)
   auto wrap_opnd = [&](int& tm, int& tn) {
-    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && a.dbg_wrap_kind != 2) {
+    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && (a.dbg_wrap_kind & 3) != 2) {
       tm %= a.dbg_wrap_m;
       tn %= a.dbg_wrap_n;
     }
   };
   auto wrap_out = [&](int& tm, int& tn) {
-    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && a.dbg_wrap_kind != 1) {
+    if (STAMP != 0 && a.dbg_wrap_m > 0 && a.dbg_wrap_m < 15 && (a.dbg_wrap_kind & 3) != 1) {
       tm %= a.dbg_wrap_m;
       tn %= a.dbg_wrap_n;
     }
