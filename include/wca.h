@@ -330,7 +330,7 @@ int wca_test_set_attn_split_drop(int mask);
 /* A/B and test switches of the library, process-wide (csrc/debug_switch.cpp; every default is the shipped choice and the product never calls
  * this): "attn_split_variant" (1: pair attention on the 16x16x32 kernel everywhere), "attn_variant" (f16 attention: 1 / 3), "head_stats_general"
  * (1: the general head-statistics kernel), "gemm_supertile" (m-panels per supertile), "ln_pair_v4", "fail_precision_alloc" (1: the next
- * precision switch fails its allocation: the roll-back test), "attn_split_drop". The environment variable of the same
+ * precision switch fails its allocation: the roll-back test), "attn_split_drop", "attn_prio" (experiment), "gemm_ring" (1: the pair GEMM on round 4's two-slot rings). The environment variable of the same
  * meaning (WCA_ATTN_SPLIT_VARIANT, ...) is read ONCE, as the switch's initial value, never per launch. */
 int wca_test_set_switch(const char* name, int value);
 /* the [batch][n_text_layer * n_text_head] head selection scores (timing.py:13-43) of the LAST fused batch, after it was fetched (no batch in

@@ -86,11 +86,12 @@ def test_split_gemm_is_fp32_accurate(eng, lib, wca, M, N, K, tile):
 
 @pytest.mark.parametrize("M,N,K,tile", [(6144, 2048, 128, 0), (6100, 2100, 256, 0), (24000, 1024, 1024, 0), (24000, 1024, 1024, 258), (12288, 1024, 4096, 0),
                                         (24064, 3072, 1024, 0)])
-def test_pair_gemm_w_tile_staged_once(eng, lib, wca, M, N, K, tile):
+def test_pair_gemm_w_tile_staged_once(eng, lib, wca, switch, M, N, K, tile):
     """The persistent 256 x 256 kernel in its SPLITW form -- A rows [hi | lo], the PLAIN W, every W K-tile staged once and its
     fragments re-used by the lo step -- against float64 at the tolerance of an fp32 GEMM, for every output mode the engine uses
     (f32 store, f32 read-modify-write, f16 store, pair store with the erf GELU), one tile per workgroup and the persistent walk
-    (more tiles than CUs), ragged M / N edges; and bit-for-bit determinism."""
+    (more tiles than CUs), ragged M / N edges; and bit-for-bit determinism. Round 5: the default LDS ring (three A slots + one W slot, the A tile
+    requested three steps ahead) must give the bits of round 4's two-slot rings (switch gemm_ring = 1): same MFMAs in the same order."""
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     a = (torch.randn(M, K, generator=g) * 0.7).cuda()
     w = (torch.randn(N, K, generator=g) * 0.1).half().cuda()
@@ -108,6 +109,12 @@ def test_pair_gemm_w_tile_staged_once(eng, lib, wca, M, N, K, tile):
     wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out_b), M, N, K, 0, 1 | ft))
     torch.cuda.synchronize()
     assert torch.equal(out, out_b)
+    switch("gemm_ring", 1)
+    out_r4 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out_r4), M, N, K, 0, 1 | ft))
+    torch.cuda.synchronize()
+    switch("gemm_ring", 0)
+    assert torch.equal(out, out_r4)
     # read-modify-write of an f32 residual
     x0 = torch.randn(M, N, generator=torch.Generator().manual_seed(5)).cuda()
     x = x0.clone()

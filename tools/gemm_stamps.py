@@ -3,7 +3,7 @@
 (diagnostic instantiation; read the SHARES, the stamps add fences) on the encoder's shapes, in the contract mode's SPLITW form and
 the f16 form, twice each: the real tile walk, and with every tile coordinate taken modulo (2, 2) so that the operand footprint
 (2 activation panels + 2 weight panels, 1.5-3 MB) is L2-resident for every XCD. Then plain timings (no stamps) of the same two walks.
-  python tools/gemm_stamps.py [B=64]"""
+  python tools/gemm_stamps.py [B=64] [t = timings only | s] [pair:fc1 | f16:qkv | ... = one shape]"""
 import ctypes as C
 import importlib
 import os
@@ -56,7 +56,7 @@ for name, n, k, mode, pairs in SHAPES:
     flags = mode | (512 if pairs else 0)
     tag = "%s %s (M=%d N=%d K=%d)" % ("pair" if pairs else "f16 ", name, M, n, k)
     nk = (2 if pairs else 1) * k // 64
-    for wrap in ((15, 2) if len(sys.argv) <= 2 else ()):   # 15 = no wrap (same diagnostic instantiation); any second argument: timings only
+    for wrap in ((15, 2) if (len(sys.argv) <= 2 or sys.argv[2] != "t") else ()):   # 15 = no wrap (same diagnostic instantiation); second argument "t": timings only
         dbg = torch.zeros(4 * 8 * 64 * 8, dtype=torch.int64, device="cuda")
         fl = flags | (wrap << 12) | (wrap << 16)
         for _ in range(3):

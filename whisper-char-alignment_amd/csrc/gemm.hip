@@ -435,8 +435,11 @@ struct GemmIntC {
 };
 
 // STAMP: 0 product; 1 s_memtime stamps (+ the tile wrap below); 2 the tile wrap alone (timing of an L2-resident operand footprint)
-template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, bool SPLITW = false>
+template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, int SPLITW_MODE = 0>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
+  // SPLITW_MODE: 0 single f16 operands; 1 pair operands, two-slot rings for A and W (round 4); 2 pair operands, THREE A slots + ONE W slot (round 5, below)
+  constexpr bool SPLITW = SPLITW_MODE != 0;
+  constexpr bool RING3 = SPLITW_MODE == 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
   constexpr int TILE256 = 256 * 64;
@@ -483,9 +486,15 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 
   // request g (0..7) of a K tile: g>>1 = row block (64 rows), g&1 = operand (A / W); 1 KiB per wave each.
   // ta / tw: byte offset of (tile row 0, K offset) in A / W.
+  // LDS ring. Two-slot form: slot b = [A K-tile | W K-tile] at b * 64 KiB. RING3 (pair operands): A K-tiles in THREE slots of 32 KiB at 0 / 32 / 64 KiB and
+  // ONE W slot at 96 KiB: a W K-tile is read from LDS only in the even step that first uses it (the odd step re-uses the register fragments), so it is dead
+  // after that step's mid barrier and the next one can land in its place; the room goes to a third A slot, which lets the A tile of step s + 3 be requested in
+  // step s -- two steps of latency cover instead of one (profiles/r05_gemm_stamps.txt: every wave spent ~360 of ~3 450 cycles per step in the vmcnt wait).
+  auto a_slot = [&](int buf) -> half_t* { return RING3 ? lds + buf * TILE256 : lds + buf * (2 * TILE256); };
+  auto w_slot = [&](int bufw) -> half_t* { return RING3 ? lds + 3 * TILE256 : lds + bufw * (2 * TILE256) + TILE256; };
   auto stage_one = [&](int buf, int bufw, unsigned ta, unsigned tw, int g) {
-    half_t* At = lds + buf * (2 * TILE256);
-    half_t* Wt = lds + bufw * (2 * TILE256) + TILE256;
+    half_t* At = a_slot(buf);
+    half_t* Wt = w_slot(bufw);
     const int i = g >> 1;
     // the wave-uniform part stays an opaque SGPR value: one v_add per request instead of eight per-lane
     // induction variables (the loop strength reduction otherwise keeps va + i*sa64 + k in 8 VGPRs and spills)
@@ -616,7 +625,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   stage_bias(0, n0);
 #pragma unroll
   for (int g = 0; g < 8; ++g) stage_one(0, 0, ta, tw, g);
-  if (nk > 1) {
+  if (RING3) {   // (nk >= 4: K % 128 == 0) A tiles of steps 1 and 2 go out with the first one; A(0) and W(0) are waited for
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) stage_one(1, 0, ta + a_koff(1), tw, g);
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) stage_one(2, 0, ta + a_koff(2), tw, g);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  } else if (nk > 1) {
 #pragma unroll
     for (int g = 0; g < 8; ++g)
       if (!SPLITW || (g & 1) == 0) stage_one(1, 1, ta + a_koff(1), tw + w_koff(1), g);  // SPLITW: step 1 multiplies the W tile of step 0
@@ -627,7 +642,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   }
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
+  WCA_LOAD_HALF(a_slot(0), w_slot(0), xb0, wb0, w0, x0);
+  int ring_a = 0;          // RING3: A slot of the current K step (runs on across tile boundaries)
+  bool a_inflight = true;  // RING3: the previous step requested an A tile (the 4 youngest DMA requests may stay in flight across this step's barrier)
 
 #define WCA_STAMP(IDX)                                                                      \
   do {                                                                                     \
@@ -664,14 +681,15 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
     // one K step; PAR >= 0: the step's parity (= its A ring slot) is a compile-time constant (SPLITW: even = first use of a W tile)
     auto kstep = [&](auto par_c, const int kt) {
       constexpr int PAR = decltype(par_c)::value;
-      const int cur = PAR >= 0 ? PAR : (kt & 1);
-      const int wslot = SPLITW ? ((kt >> 1) & 1) : cur;                 // W ring slot of this step
+      const int cur = RING3 ? ring_a : (PAR >= 0 ? PAR : (kt & 1));
+      const int nxt = RING3 ? (ring_a == 2 ? 0 : ring_a + 1) : (cur ^ 1);   // A slot of step kt + 1
+      const int wslot = SPLITW ? ((kt >> 1) & 1) : cur;                 // W ring slot of this step (RING3: one slot, w_slot() ignores it)
       const int wslot_n = SPLITW ? (((kt + 1) >> 1) & 1) : (cur ^ 1);   // ... of step kt + 1
       // this step's W fragments are new (SPLITW, odd step: those of the step before); wave-uniform
       const bool W_FRESH = !SPLITW || (PAR >= 0 ? PAR == 0 : (kt & 1) == 0);
       const bool W_NEXT_FRESH = !SPLITW || (PAR >= 0 ? PAR == 1 : (kt & 1) == 1);
-      const half_t* At = lds + cur * (2 * TILE256);
-      const half_t* Wt = lds + wslot * (2 * TILE256) + TILE256;
+      const half_t* At = a_slot(cur);
+      const half_t* Wt = w_slot(wslot);
       WCA_STAMP(0);
       // ---- K half 0 (fragments w0/x0 were fetched under the previous step's half 1). The 12 fragment reads of
       // half 1 are issued two at a time between groups of 4 MFMAs.
@@ -694,8 +712,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(1);
-      // all ds_reads of slot `cur` are retired; K step s+1 (the only DMA in flight) has landed
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      // all ds_reads of slot `cur` are retired; K step s+1 has landed. Two-slot rings: it is the only DMA in flight. RING3: the 4 youngest requests are
+      // the A tile of step s+2 (requested in the previous step AFTER that step's W requests) and stay in flight across the barrier.
+      if (RING3 && a_inflight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -711,8 +731,12 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       const unsigned ka = (in_tile2 ? ta + a_koff(kt + 2) : tan + a_koff(kt + 2 - nk));
       const unsigned kw = (in_tile2 ? tw + w_koff(kt + 2) : twn + w_koff(kt + 2 - nk));
       const int wslot_2 = SPLITW ? (wslot ^ 1) : cur;   // W ring slot of step kt + 2
-      const half_t* An = lds + (cur ^ 1) * (2 * TILE256);
-      const half_t* Wn = lds + wslot_n * (2 * TILE256) + TILE256;
+      const half_t* An = a_slot(nxt);
+      const half_t* Wn = w_slot(wslot_n);
+      // RING3: the A tile requested in this step is the one of step kt + 3 (into the slot this step just finished reading)
+      const bool in_tile3 = kt + 3 < nk;
+      const bool more3 = in_tile3 || has_next;
+      const unsigned ka3 = (in_tile3 ? ta + a_koff(kt + 3) : tan + a_koff(kt + 3 - nk));
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         __builtin_amdgcn_s_setprio(1);
@@ -720,7 +744,21 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (more2 && (W_FRESH || (g & 1) == 0)) stage_one(cur, wslot_2, ka, kw, g);
+        if (RING3) {
+          // even steps: the 4 W requests FIRST (groups 0-3: they are needed one step from now and must be older than the A requests the next wait leaves
+          // in flight), then the 4 A requests (groups 4-7); odd steps: the 4 A requests in every second group
+          if (W_FRESH) {
+            if (g < 4) {
+              if (more2) stage_one(cur, 0, ka3, kw, 2 * g + 1);
+            } else if (more3) {
+              stage_one(cur, 0, ka3, kw, 2 * (g - 4));
+            }
+          } else if ((g & 1) == 0 && more3) {
+            stage_one(cur, 0, ka3, kw, g);
+          }
+        } else if (more2 && (W_FRESH || (g & 1) == 0)) {
+          stage_one(cur, wslot_2, ka, kw, g);
+        }
         if (more1) {
           if (g < 2) {
             if (W_NEXT_FRESH) {
@@ -735,6 +773,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(4);
+      if (RING3) {
+        ring_a = nxt;
+        a_inflight = more3;
+      }
     };
     // (SPLITW with the step parity as a compile-time constant -- the loop unrolled by two -- spills 70-90 VGPRs: both steps' LDS
     //  base addresses stay live; the runtime parity costs two scalar branches per step)
@@ -778,7 +820,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // K tile 0 of the new tile landed before the last mid-tile barrier; its fragments are fetched only now so
     // that they are not live across the epilogue (that cost 13-18 spilled VGPRs)
-    WCA_LOAD_HALF(lds, lds + TILE256, xb0, wb0, w0, x0);
+    WCA_LOAD_HALF(a_slot(RING3 ? ring_a : 0), w_slot(0), xb0, wb0, w0, x0);
   }
 #undef WCA_STAMP
 #undef WCA_LOAD_HALF
@@ -949,6 +991,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     n_cu_cache[dev & 31].store(n_cu, std::memory_order_relaxed);
   }
   if (a.cu_limit > 0 && a.cu_limit < n_cu) n_cu = a.cu_limit;   // a CU-masked stream: one persistent workgroup per CU it owns
+  // pair operands on the persistent kernel: three A slots + one W slot (round 5); the switch gemm_ring = 1 keeps round 4's two-slot rings (A/B, tests)
+  const int ring = splitw ? (debug_switch(DBG_GEMM_RING) == 1 ? 1 : 2) : 0;
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
@@ -1009,20 +1053,21 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (e != hipSuccess) return e;                                                                \
     hipLaunchKernelGGL((KERN<OM, G, S, ST, SW>), grid, block, shmem, s, a);                       \
   } while (0)
-#define WCA_LAUNCH_K5(KERN, OM, G, S)                                                              \
+#define WCA_LAUNCH_K5R(KERN, OM, G, S, RING)                                                        \
   do {                                                                                              \
     static std::atomic<unsigned> attr_mask5{0};                                                     \
     if (!(attr_mask5.load(std::memory_order_acquire) & (1u << (dev & 31)))) {                       \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, 0, true>), \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<OM, G, S, 0, RING>), \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);   \
       if (e != hipSuccess) return e;                                                                \
       attr_mask5.fetch_or(1u << (dev & 31), std::memory_order_release);                             \
     }                                                                                               \
-    hipLaunchKernelGGL((KERN<OM, G, S, 0, true>), grid, block, shmem, s, a);                        \
+    hipLaunchKernelGGL((KERN<OM, G, S, 0, RING>), grid, block, shmem, s, a);                        \
   } while (0)
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
-    if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 4); else if ((S) == 3) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 3); else if ((S) == 2) WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 2); else WCA_LAUNCH_K5(gemm256p_f16_kernel, OM, G, 1); } \
+    if (pipelined && splitw && ring == 1) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 1); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 1); } \
+    else if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 2); else if ((S) == 3) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 3, 2); else if ((S) == 2) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 2, 2); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 2); } \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \
@@ -1046,15 +1091,20 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     if (a.dbg != nullptr) WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, 1, 1, SW);          \
     else WCA_LAUNCH_K4(gemm256p_f16_kernel, OM, G, 1, 2, SW);                           \
   } while (0)
-    if (splitw) {
-      if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, true);
-      else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, true);
-      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, true);
+    if (splitw && ring == 1) {
+      if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 1);
+      else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, 1);
+      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, 1);
+      else return hipErrorInvalidValue;
+    } else if (splitw) {
+      if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 2);
+      else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, 2);
+      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, 2);
       else return hipErrorInvalidValue;
     } else {
-      if (a.out_mode == 0 && a.gelu) WCA_LAUNCH_DIAG(0, true, false);
-      else if (a.out_mode == 0) WCA_LAUNCH_DIAG(0, false, false);
-      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, false);
+      if (a.out_mode == 0 && a.gelu) WCA_LAUNCH_DIAG(0, true, 0);
+      else if (a.out_mode == 0) WCA_LAUNCH_DIAG(0, false, 0);
+      else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, 0);
       else return hipErrorInvalidValue;
     }
 #undef WCA_LAUNCH_DIAG
@@ -1092,7 +1142,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #undef WCA_LAUNCH_S
 #undef WCA_LAUNCH_K
 #undef WCA_LAUNCH_K4
-#undef WCA_LAUNCH_K5
+#undef WCA_LAUNCH_K5R
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

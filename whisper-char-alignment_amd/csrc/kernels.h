@@ -9,7 +9,7 @@ typedef _Float16 half_t;
 
 // ---------------------------------------------------------------- A/B and test switches (debug_switch.cpp; wca_test_set_switch)
 enum { DBG_ATTN_SPLIT_VARIANT = 0, DBG_ATTN_VARIANT, DBG_HEAD_STATS_GENERAL, DBG_GEMM_SUPERTILE, DBG_LN_PAIR_V4, DBG_FAIL_PRECISION_ALLOC,
-       DBG_ATTN_SPLIT_DROP, DBG_SWITCH_COUNT };
+       DBG_ATTN_SPLIT_DROP, DBG_ATTN_PRIO, DBG_GEMM_RING, DBG_SWITCH_COUNT };
 int debug_switch(int id);                            // current value (its environment variable, if any, read once as the initial value)
 int set_debug_switch(const char* name, int value);   // 0, or -1 for an unknown name
 
@@ -107,6 +107,7 @@ struct AttnArgs {
   // attn_split_kernel: S = Qhi.Khi + Qhi.Klo + Qlo.Khi, O = Phi.Vhi + Phi.Vlo + Plo.Vhi, fp32 softmax on the exact logits.
   int split;
   long q_lo, k_lo, v_lo, o_lo;
+  int prio_mode;                           // experiment (switch attn_prio): static issue priority for one of the two waves that share a SIMD
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s);  // attention_split.hip (launch_attention forwards a.split != 0 here)
