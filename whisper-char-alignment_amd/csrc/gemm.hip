@@ -488,8 +488,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // ta / tw: byte offset of (tile row 0, K offset) in A / W.
   // LDS ring. Two-slot form: slot b = [A K-tile | W K-tile] at b * 64 KiB. RING3 (pair operands): A K-tiles in THREE slots of 32 KiB at 0 / 32 / 64 KiB and
   // ONE W slot at 96 KiB: a W K-tile is read from LDS only in the even step that first uses it (the odd step re-uses the register fragments), so it is dead
-  // after that step's mid barrier and the next one can land in its place; the room goes to a third A slot, which lets the A tile of step s + 3 be requested in
-  // step s -- two steps of latency cover instead of one (profiles/r05_gemm_stamps.txt: every wave spent ~360 of ~3 450 cycles per step in the vmcnt wait).
+  // after that step's mid barrier and the next one can land in its place; the room goes to a third A slot, so that the A tile of step s + 2 can be requested
+  // already in HALF 0 of step s (into the slot of step s - 1) and stays in flight across the step's barrier (counted vmcnt(4)): the DMA requests spread over
+  // both halves (4 + 4 instead of 0 + 8) and get 1.3 steps of latency cover instead of 0.5-1 (profiles/r05_gemm_stamps.txt: every wave spent ~360 of
+  // ~3 450 cycles per step in the vmcnt wait, and half 1 with its 8 requests took 1 600-2 000 cycles against 770-960 for half 0).
   auto a_slot = [&](int buf) -> half_t* { return RING3 ? lds + buf * TILE256 : lds + buf * (2 * TILE256); };
   auto w_slot = [&](int bufw) -> half_t* { return RING3 ? lds + 3 * TILE256 : lds + bufw * (2 * TILE256) + TILE256; };
   auto stage_one = [&](int buf, int bufw, unsigned ta, unsigned tw, int g) {
@@ -625,13 +627,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   stage_bias(0, n0);
 #pragma unroll
   for (int g = 0; g < 8; ++g) stage_one(0, 0, ta, tw, g);
-  if (RING3) {   // (nk >= 4: K % 128 == 0) A tiles of steps 1 and 2 go out with the first one; A(0) and W(0) are waited for
-#pragma unroll
-    for (int g = 0; g < 8; g += 2) stage_one(1, 0, ta + a_koff(1), tw, g);
-#pragma unroll
-    for (int g = 0; g < 8; g += 2) stage_one(2, 0, ta + a_koff(2), tw, g);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else if (nk > 1) {
+  if (nk > 1) {
 #pragma unroll
     for (int g = 0; g < 8; ++g)
       if (!SPLITW || (g & 1) == 0) stage_one(1, 1, ta + a_koff(1), tw + w_koff(1), g);  // SPLITW: step 1 multiplies the W tile of step 0
@@ -644,7 +640,6 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   asm volatile("" ::: "memory");
   WCA_LOAD_HALF(a_slot(0), w_slot(0), xb0, wb0, w0, x0);
   int ring_a = 0;          // RING3: A slot of the current K step (runs on across tile boundaries)
-  bool a_inflight = true;  // RING3: the previous step requested an A tile (the 4 youngest DMA requests may stay in flight across this step's barrier)
 
 #define WCA_STAMP(IDX)                                                                      \
   do {                                                                                     \
@@ -690,6 +685,12 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       const bool W_NEXT_FRESH = !SPLITW || (PAR >= 0 ? PAR == 1 : (kt & 1) == 1);
       const half_t* At = a_slot(cur);
       const half_t* Wt = w_slot(wslot);
+      // K step kt + 2 (of this tile, or of the next one): its A tile and, on even steps, its W tile are requested during this step
+      const bool in_tile2 = kt + 2 < nk;
+      const bool more1 = kt + 1 < nk, more2 = in_tile2 || has_next;
+      const unsigned ka = (in_tile2 ? ta + a_koff(kt + 2) : tan + a_koff(kt + 2 - nk));
+      const unsigned kw = (in_tile2 ? tw + w_koff(kt + 2) : twn + w_koff(kt + 2 - nk));
+      const int prv = RING3 ? (ring_a == 0 ? 2 : ring_a - 1) : 0;   // RING3: the A slot of step kt - 1 = of step kt + 2 (every wave is past that step's barrier)
       WCA_STAMP(0);
       // ---- K half 0 (fragments w0/x0 were fetched under the previous step's half 1). The 12 fragment reads of
       // half 1 are issued two at a time between groups of 4 MFMAs.
@@ -709,12 +710,15 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
           x1[2 * (g - 2)] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2)) * 1024);
           x1[2 * (g - 2) + 1] = *reinterpret_cast<const half8*>(At + xb1 + (2 * (g - 2) + 1) * 1024);
         }
+        // RING3: the A tile of step kt + 2 goes out HERE, in half 0 (the two-slot ring cannot: its target slot is still being read), one request in every
+        // second group; half 1 keeps only the W requests of the even steps -- at most 4 DMA requests per half instead of 8 in half 1
+        if (RING3 && (g & 1) == 0 && more2) stage_one(prv, 0, ka, kw, g);
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(1);
       // all ds_reads of slot `cur` are retired; K step s+1 has landed. Two-slot rings: it is the only DMA in flight. RING3: the 4 youngest requests are
-      // the A tile of step s+2 (requested in the previous step AFTER that step's W requests) and stay in flight across the barrier.
-      if (RING3 && a_inflight) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      // the A tile of step s+2 just requested in half 0 (younger than the W requests of the previous step's half 1) and stay in flight across the barrier.
+      if (RING3 && more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
@@ -726,17 +730,9 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       // issue last (measured with s_memtime stamps: ~1000 cycles of barrier skew per K tile).
       // SPLITW: the W tile of step s+2 is new only when s is even (it goes to the W slot that step s-1 read last: every wave is
       // past that step's barrier), and the next step's W fragments are re-fetched only when s is odd.
-      const bool in_tile2 = kt + 2 < nk;
-      const bool more1 = kt + 1 < nk, more2 = in_tile2 || has_next;
-      const unsigned ka = (in_tile2 ? ta + a_koff(kt + 2) : tan + a_koff(kt + 2 - nk));
-      const unsigned kw = (in_tile2 ? tw + w_koff(kt + 2) : twn + w_koff(kt + 2 - nk));
       const int wslot_2 = SPLITW ? (wslot ^ 1) : cur;   // W ring slot of step kt + 2
       const half_t* An = a_slot(nxt);
       const half_t* Wn = w_slot(wslot_n);
-      // RING3: the A tile requested in this step is the one of step kt + 3 (into the slot this step just finished reading)
-      const bool in_tile3 = kt + 3 < nk;
-      const bool more3 = in_tile3 || has_next;
-      const unsigned ka3 = (in_tile3 ? ta + a_koff(kt + 3) : tan + a_koff(kt + 3 - nk));
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         __builtin_amdgcn_s_setprio(1);
@@ -745,17 +741,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (RING3) {
-          // even steps: the 4 W requests FIRST (groups 0-3: they are needed one step from now and must be older than the A requests the next wait leaves
-          // in flight), then the 4 A requests (groups 4-7); odd steps: the 4 A requests in every second group
-          if (W_FRESH) {
-            if (g < 4) {
-              if (more2) stage_one(cur, 0, ka3, kw, 2 * g + 1);
-            } else if (more3) {
-              stage_one(cur, 0, ka3, kw, 2 * (g - 4));
-            }
-          } else if ((g & 1) == 0 && more3) {
-            stage_one(cur, 0, ka3, kw, g);
-          }
+          if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);   // the W tile of step kt + 2 into the one W slot (dead since this step's barrier)
         } else if (more2 && (W_FRESH || (g & 1) == 0)) {
           stage_one(cur, wslot_2, ka, kw, g);
         }
@@ -773,10 +759,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(4);
-      if (RING3) {
-        ring_a = nxt;
-        a_inflight = more3;
-      }
+      if (RING3) ring_a = nxt;
     };
     // (SPLITW with the step parity as a compile-time constant -- the loop unrolled by two -- spills 70-90 VGPRs: both steps' LDS
     //  base addresses stay live; the runtime parity costs two scalar branches per step)
