@@ -320,7 +320,8 @@ int wca_test_gemm_rows(wca_engine* e, const void* a_f16_dev, const float* x_f32_
  * out_mode: bits 0-7 as wca_test_gemm (0 / 2 / 4), bit 8 GELU, bit 9 pair operands (a = [M][hi(K) | lo(K)], plain w: the SPLITW form),
  * bits 12-15 / 16-19: when non-zero, tile coordinates are taken modulo these (m, n) -- an L2-resident operand footprint, outputs
  * collide; with the wrap set dbg_dev may be NULL (no stamps: plain timing of the wrapped launch); bits 20-21: 0 wrap operand and output
- * addresses, 1 operand addresses only, 2 output addresses only; bit 22: every LDS-DMA piece reads 1 KiB of contiguous memory (timing only) */
+ * addresses, 1 operand addresses only, 2 output addresses only; bit 22: every LDS-DMA piece reads 1 KiB of contiguous memory (timing only);
+ * bits 24-26: experiment form of the pair kernel's K loop (fc1 shape only; gemm.hip SPLITW_MODE 3-6) */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
                           int out_mode, unsigned long long* dbg_dev);
 /* diagnostic, process-wide (the product never calls it; 0 = the contract's three passes per product): leave single MFMA passes out of the

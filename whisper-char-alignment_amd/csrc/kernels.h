@@ -44,6 +44,7 @@ struct GemmArgs {
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
+  int dbg_variant;         // diagnostic builds only: experiment form of the RING3 loop (0 = the product's)
   int dbg_wrap_kind;       // diagnostic builds only: bits 0-1: 0 wrap operand AND output addresses, 1 operands only, 2 outputs only; bit 2: packed (contiguous) DMA sources
   int dbg_wrap_m, dbg_wrap_n; // diagnostic builds only: tile coordinates taken modulo these (an L2-resident operand footprint; outputs collide)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
