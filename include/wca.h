@@ -320,8 +320,7 @@ int wca_test_gemm_rows(wca_engine* e, const void* a_f16_dev, const float* x_f32_
  * out_mode: bits 0-7 as wca_test_gemm (0 / 2 / 4), bit 8 GELU, bit 9 pair operands (a = [M][hi(K) | lo(K)], plain w: the SPLITW form),
  * bits 12-15 / 16-19: when non-zero, tile coordinates are taken modulo these (m, n) -- an L2-resident operand footprint, outputs
  * collide; with the wrap set dbg_dev may be NULL (no stamps: plain timing of the wrapped launch); bits 20-21: 0 wrap operand and output
- * addresses, 1 operand addresses only, 2 output addresses only; bit 22: every LDS-DMA piece reads 1 KiB of contiguous memory (timing only);
- * bits 24-26: experiment form of the pair kernel's K loop (fc1 shape only; gemm.hip SPLITW_MODE 3-6) */
+ * addresses, 1 operand addresses only, 2 output addresses only; bit 22: every LDS-DMA piece reads 1 KiB of contiguous memory (timing only) */
 int wca_test_gemm_stamped(wca_engine* e, const void* a_f16_dev, const void* w_f16_dev, void* c_dev, int M, int N, int K,
                           int out_mode, unsigned long long* dbg_dev);
 /* diagnostic, process-wide (the product never calls it; 0 = the contract's three passes per product): leave single MFMA passes out of the
@@ -331,7 +330,7 @@ int wca_test_set_attn_split_drop(int mask);
 /* A/B and test switches of the library, process-wide (csrc/debug_switch.cpp; every default is the shipped choice and the product never calls
  * this): "attn_split_variant" (1: pair attention on the 16x16x32 kernel everywhere), "attn_variant" (f16 attention: 1 / 3), "head_stats_general"
  * (1: the general head-statistics kernel), "gemm_supertile" (m-panels per supertile), "ln_pair_v4", "fail_precision_alloc" (1: the next
- * precision switch fails its allocation: the roll-back test), "attn_split_drop", "attn_prio" (experiment), "gemm_ring" (1: the pair GEMM on round 4's two-slot rings). The environment variable of the same
+ * precision switch fails its allocation: the roll-back test), "attn_split_drop", "gemm_ring" (1: the pair GEMM on round 4's two-slot rings). The environment variable of the same
  * meaning (WCA_ATTN_SPLIT_VARIANT, ...) is read ONCE, as the switch's initial value, never per launch. */
 int wca_test_set_switch(const char* name, int value);
 /* the [batch][n_text_layer * n_text_head] head selection scores (timing.py:13-43) of the LAST fused batch, after it was fetched (no batch in

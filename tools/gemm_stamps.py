@@ -95,11 +95,4 @@ for name, n, k, mode, pairs in SHAPES:
         fl = flags | (wr << 12) | (wr << 16) | (kind << 20)
         t[label] = min(timeit(lambda: chk(lib.wca_test_gemm_stamped(eng._h, vp(A), vp(w), vp(out), M, n, k, fl, None))) for _ in range(3))
     print("%s timing: " % tag + "  ".join("%s %.3f ms" % kv for kv in t.items()), flush=True)
-    if pairs and name == "fc1":   # experiment forms of the RING3 loop (SPLITW_MODE 3-6), interleaved with the product form's diagnostic instantiation
-        tv = {}
-        for rep in range(3):
-            for label, var in (("product loop", 0), ("no setprio toggles", 3), ("no toggles + static priority waves 4-7", 4), ("early fragment reads", 5), ("early reads + static priority", 6)):
-                fl = flags | (15 << 12) | (15 << 16) | (var << 24)
-                tv[label] = min(tv.get(label, 1e9), timeit(lambda: chk(lib.wca_test_gemm_stamped(eng._h, vp(A), vp(w), vp(out), M, n, k, fl, None))))
-        print("%s K-loop experiment forms: " % tag + "  ".join("%s %.3f ms" % kv for kv in tv.items()), flush=True)
     del a, hi, A, w, out

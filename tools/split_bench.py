@@ -88,7 +88,6 @@ def main():
     qh, kh, vh = q.half(), k_.half(), v.half()
     o, o2 = torch.empty_like(qh), torch.empty_like(q2)
     t16, t3, t3o = [], [], []
-    tp = {1: [], 2: [], 3: []}
     for _ in range(reps):   # interleaved: f16, pair 32x32x16 (the launcher's choice), pair 16x16x32 (switch attn_split_variant = 1)
         t16.append(timeit(lambda: chk(lib.wca_test_attention(eng._h, vp(qh), vp(kh), vp(vh), vp(o), None, 0, 0, B, H, S, S, 0))))
         chk(lib.wca_test_set_switch(b"attn_split_variant", 0))
@@ -96,14 +95,9 @@ def main():
         chk(lib.wca_test_set_switch(b"attn_split_variant", 1))
         t3o.append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
         chk(lib.wca_test_set_switch(b"attn_split_variant", 0))
-        for pm in tp:   # experiment: static issue priority for one of the two waves of a SIMD (by wave slot, inverted, by workgroup parity)
-            chk(lib.wca_test_set_switch(b"attn_prio", pm))
-            tp[pm].append(timeit(lambda: chk(lib.wca_test_attention_split(eng._h, vp(q2), vp(k2), vp(v2), vp(o2), None, 0, 0, B, H, S, S, 0))))
-            chk(lib.wca_test_set_switch(b"attn_prio", 0))
     fl = 4.0 * B * H * S * S * 64
     print("attn enc B=%d H=%d S=%d  f16 %.3f ms (%.0f TF)  pair 32x32x16 %.3f ms (%.0f TF alg)  pair 16x16x32 %.3f ms (%.0f TF alg)"
           % (B, H, S, min(t16), fl / min(t16) / 1e9, min(t3), fl / min(t3) / 1e9, min(t3o), fl / min(t3o) / 1e9), flush=True)
-    print("attn enc pair 32x32x16 with a static priority for one wave of each SIMD: " + "  ".join("mode %d %.3f ms" % (pm, min(v)) for pm, v in tp.items()), flush=True)
 
 if __name__ == "__main__":
     main()

@@ -484,15 +484,9 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
   const int b = bh / a.H, h = bh - b * a.H;
   const int q_wave = (lid - bh * n_qt) * QB + wave * 32;
   const int qrow = q_wave + l31;
-  // EXPERIMENT (switch attn_prio): the two waves that share a SIMD belong to two independent workgroups and run the same program; PMC says their matrix and
-  // vector phases barely overlap (co-execution 10 %). A STATIC priority for one of them lets that wave run as if alone and the other fill its gaps.
-  if (a.prio_mode != 0) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    const unsigned sel = a.prio_mode == 3 ? (unsigned)(blockIdx.x & 1) : ((hwid & 1u) ^ (a.prio_mode == 2 ? 1u : 0u));
-    if (sel) __builtin_amdgcn_s_setprio(3);
-  }
-
+  // (Round-5 experiment, removed: a STATIC issue priority for one of the two waves that share a SIMD -- they belong to two independent workgroups, run the same
+  //  program, and PMC shows their matrix and vector phases co-executing only 10 % of the time -- chosen by wave slot (s_getreg HW_ID) or by workgroup parity:
+  //  1.703 / 1.695 / 1.670 ms against 1.678-1.690 ms for the symmetric kernel at 64 x 16 x 1500 x 1500: nothing.)
   // Q fragments (B operand of S^T): lane holds Q[q = l31][dim = 16 ks + 8 hh + j]; the pair is multiplied by scale * log2(e) once and
   // split again, so the scores leave the MFMAs in the log2 domain
   const float c_log2 = a.scale * LOG2E;
@@ -794,9 +788,7 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
 
 }  // namespace
 
-hipError_t launch_attention_split(const AttnArgs& a_in, hipStream_t s) {
-  AttnArgs a = a_in;
-  if (a.prio_mode == 0) a.prio_mode = debug_switch(DBG_ATTN_PRIO);
+hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s) {
   if (a.nq <= 0 || a.B <= 0) return hipSuccess;
   if (a.nk <= 0) return hipErrorInvalidValue;
   if ((a.q_rs % 8) || (a.k_rs % 8) || (a.v_rs % 8) || (a.o_rs % 4)) return hipErrorInvalidValue;

@@ -25,7 +25,6 @@ Sw g_sw[DBG_SWITCH_COUNT] = {
     {"ln_pair_v4", "WCA_LN_PAIR_V4", {0}, {0}},                     // 1: the four-wide pair LayerNorm
     {"fail_precision_alloc", "WCA_TEST_FAIL_PRECISION_ALLOC", {0}, {0}},  // 1: inject an allocation failure into wca_set_precision_sites
     {"attn_split_drop", nullptr, {0}, {0}},                         // pass mask of the encoder's pair attention (wca_test_set_attn_split_drop)
-    {"attn_prio", "WCA_ATTN_PRIO", {0}, {0}},                       // experiment: static issue priority by wave slot (1 / 2) or workgroup parity (3)
     {"gemm_ring", "WCA_GEMM_RING", {0}, {0}},                       // 1: the pair GEMM on round 4's two-slot rings (default: three A slots + one W slot)
 };
 }  // namespace

@@ -2937,7 +2937,6 @@ int wca_test_gemm_stamped(wca_engine* e, const void* a, const void* w, void* c, 
   g.dbg_wrap_m = wrap_m;
   g.dbg_wrap_n = wrap_n;
   g.dbg_wrap_kind = (out_mode >> 20) & 7;
-  g.dbg_variant = (out_mode >> 24) & 7;
   HIPCHK(launch_gemm(g, e->stream));
   return WCA_OK;
 }

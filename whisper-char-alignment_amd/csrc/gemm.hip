@@ -439,13 +439,10 @@ template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, int SPLITW_MODE = 0>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // SPLITW_MODE: 0 single f16 operands; 1 pair operands, two-slot rings for A and W (round 4); 2 pair operands, THREE A slots + ONE W slot (round 5, below)
   constexpr bool SPLITW = SPLITW_MODE != 0;
-  constexpr bool RING3 = SPLITW_MODE >= 2;
-  // experiment forms of the RING3 loop (diagnostic instantiations only, tools/gemm_stamps.py): 3 no s_setprio toggles around the MFMA groups; 4 no toggles and
-  // a static priority for waves 4-7 (the arbitration losers of every SIMD: the critical path of the step); 5 half 0's fragment reads three per group in groups
-  // 0-3 (retired four groups before the step's wait instead of two); 6 = 4 + 5
-  constexpr bool PRIO_TOGGLE = SPLITW_MODE != 3 && SPLITW_MODE != 4 && SPLITW_MODE != 6;
-  constexpr bool PRIO_STATIC47 = SPLITW_MODE == 4 || SPLITW_MODE == 6;
-  constexpr bool EARLY_READS = SPLITW_MODE == 5 || SPLITW_MODE == 6;
+  constexpr bool RING3 = SPLITW_MODE == 2;
+  // (Round-5 experiment forms of the RING3 loop, measured on the fc1 shape and removed: no s_setprio toggles around the MFMA groups 1.488 ms, no toggles + a static
+  //  priority for waves 4-7 -- the arbitration losers of every SIMD, the critical path of the step -- 1.500, half 0's fragment reads three per group in groups 0-3
+  //  1.509, both 1.500, against 1.497 ms for this loop: nothing.)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   half_t* lds = reinterpret_cast<half_t*>(smem);
   constexpr int TILE256 = 256 * 64;
@@ -646,7 +643,6 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   asm volatile("" ::: "memory");
   WCA_LOAD_HALF(a_slot(0), w_slot(0), xb0, wb0, w0, x0);
   int ring_a = 0;          // RING3: A slot of the current K step (runs on across tile boundaries)
-  if (PRIO_STATIC47 && wave >= 4) __builtin_amdgcn_s_setprio(1);
 
 #define WCA_STAMP(IDX)                                                                      \
   do {                                                                                     \
@@ -703,21 +699,12 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       // half 1 are issued two at a time between groups of 4 MFMAs.
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        if (PRIO_TOGGLE) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[nt], x0[g], acc[g][nt], 0, 0, 0);
-        if (PRIO_TOGGLE) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (EARLY_READS) {
-          if (g < 2 && W_FRESH) {
-            w1[2 * g] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g) * 1024);
-            w1[2 * g + 1] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g + 1) * 1024);
-          }
-          if (g < 4) {
-            x1[2 * g] = *reinterpret_cast<const half8*>(At + xb1 + (2 * g) * 1024);
-            x1[2 * g + 1] = *reinterpret_cast<const half8*>(At + xb1 + (2 * g + 1) * 1024);
-          }
-        } else if (g < 2) {
+        if (g < 2) {
           if (W_FRESH) {
             w1[2 * g] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g) * 1024);
             w1[2 * g + 1] = *reinterpret_cast<const half8*>(Wt + wb1 + (2 * g + 1) * 1024);
@@ -751,10 +738,10 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       const half_t* Wn = w_slot(wslot_n);
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
-        if (PRIO_TOGGLE) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
-        if (PRIO_TOGGLE) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (RING3) {
           if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);   // the W tile of step kt + 2 into the one W slot (dead since this step's barrier)
@@ -1095,12 +1082,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, 1);
       else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, 1);
       else return hipErrorInvalidValue;
-    } else if (splitw && a.dbg_variant >= 3 && a.dbg_variant <= 6) {   // experiment forms of the RING3 loop: the fc1 kernel only
-      if (!(a.out_mode == 4 && a.gelu)) return hipErrorInvalidValue;
-      if (a.dbg_variant == 3) WCA_LAUNCH_DIAG(4, true, 3);
-      else if (a.dbg_variant == 4) WCA_LAUNCH_DIAG(4, true, 4);
-      else if (a.dbg_variant == 5) WCA_LAUNCH_DIAG(4, true, 5);
-      else WCA_LAUNCH_DIAG(4, true, 6);
     } else if (splitw) {
       if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 2);
       else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, 2);

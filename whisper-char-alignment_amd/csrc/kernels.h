@@ -9,7 +9,7 @@ typedef _Float16 half_t;
 
 // ---------------------------------------------------------------- A/B and test switches (debug_switch.cpp; wca_test_set_switch)
 enum { DBG_ATTN_SPLIT_VARIANT = 0, DBG_ATTN_VARIANT, DBG_HEAD_STATS_GENERAL, DBG_GEMM_SUPERTILE, DBG_LN_PAIR_V4, DBG_FAIL_PRECISION_ALLOC,
-       DBG_ATTN_SPLIT_DROP, DBG_ATTN_PRIO, DBG_GEMM_RING, DBG_SWITCH_COUNT };
+       DBG_ATTN_SPLIT_DROP, DBG_GEMM_RING, DBG_SWITCH_COUNT };
 int debug_switch(int id);                            // current value (its environment variable, if any, read once as the initial value)
 int set_debug_switch(const char* name, int value);   // 0, or -1 for an unknown name
 
@@ -44,7 +44,6 @@ struct GemmArgs {
                            //    exchanged between the N/256 workgroups that share a 256-row panel (gemm_epilogue.h)
   unsigned a_bytes, w_bytes; // valid bytes behind A / W (buffer-descriptor bounds); 0 => derived for flat layouts
   unsigned long long* dbg; // diagnostic builds only: s_memtime stamps (never set by the product path)
-  int dbg_variant;         // diagnostic builds only: experiment form of the RING3 loop (0 = the product's)
   int dbg_wrap_kind;       // diagnostic builds only: bits 0-1: 0 wrap operand AND output addresses, 1 operands only, 2 outputs only; bit 2: packed (contiguous) DMA sources
   int dbg_wrap_m, dbg_wrap_n; // diagnostic builds only: tile coordinates taken modulo these (an L2-resident operand footprint; outputs collide)
   int force_tile;          // 0 auto, 128 or 256: force a tile shape (tests)
@@ -108,7 +107,6 @@ struct AttnArgs {
   // attn_split_kernel: S = Qhi.Khi + Qhi.Klo + Qlo.Khi, O = Phi.Vhi + Phi.Vlo + Plo.Vhi, fp32 softmax on the exact logits.
   int split;
   long q_lo, k_lo, v_lo, o_lo;
-  int prio_mode;                           // experiment (switch attn_prio): static issue priority for one of the two waves that share a SIMD
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 hipError_t launch_attention_split(const AttnArgs& a, hipStream_t s);  // attention_split.hip (launch_attention forwards a.split != 0 here)
