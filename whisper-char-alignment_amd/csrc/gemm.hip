@@ -744,7 +744,11 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (RING3) {
-          if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);   // the W tile of step kt + 2 into the one W slot (dead since this step's barrier)
+          // the W tile of step kt + 2 into the one W slot (dead since this step's barrier), one request in every second group. (Measured alternatives, both
+          // slower: the 4 W requests in groups 4-7 -- fc1 -0.4 % instead of -2.9 % against the two-slot rings; two of the odd steps' A requests moved from half 0
+          // into their request-free half 1 -- every shape SLOWER than the two-slot rings: a request right behind the barrier, where all eight waves issue at the
+          // same instant, costs far more than one in half 0, where the SIMD partners are ~400 cycles apart.)
+          if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);
         } else if (more2 && (W_FRESH || (g & 1) == 0)) {
           stage_one(cur, wslot_2, ka, kw, g);
         }
