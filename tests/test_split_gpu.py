@@ -109,12 +109,13 @@ def test_pair_gemm_w_tile_staged_once(eng, lib, wca, switch, M, N, K, tile):
     wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out_b), M, N, K, 0, 1 | ft))
     torch.cuda.synchronize()
     assert torch.equal(out, out_b)
-    switch("gemm_ring", 1)
-    out_r4 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
-    wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out_r4), M, N, K, 0, 1 | ft))
-    torch.cuda.synchronize()
-    switch("gemm_ring", 0)
-    assert torch.equal(out, out_r4)
+    for ring in (1, 3):   # 1: round 4's two-slot rings; 3: the three-slot ring with waves 0-3 issuing every in-loop request
+        switch("gemm_ring", ring)
+        out_r = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out_r), M, N, K, 0, 1 | ft))
+        torch.cuda.synchronize()
+        switch("gemm_ring", 0)
+        assert torch.equal(out, out_r), ring
     # read-modify-write of an f32 residual
     x0 = torch.randn(M, N, generator=torch.Generator().manual_seed(5)).cuda()
     x = x0.clone()
