@@ -439,10 +439,10 @@ template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, int SPLITW_MODE = 0>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // SPLITW_MODE: 0 single f16 operands; 1 pair operands, two-slot rings for A and W (round 4); 2 pair operands, THREE A slots + ONE W slot (round 5, below)
   constexpr bool SPLITW = SPLITW_MODE != 0;
-  constexpr bool RING3 = SPLITW_MODE >= 2;
-  // SPLITW_MODE 3 (form C): like 2, but ONLY waves 0-3 issue the in-loop DMA requests (two row groups each). The stamps show waves 0-3 winning every issue
-  // arbitration against their SIMD partners 4-7 and then idling ~680 cycles at the step's barrier, while waves 4-7 are the critical path: the requests move to the slack.
-  constexpr bool LOADER03 = SPLITW_MODE == 3;
+  constexpr bool RING3 = SPLITW_MODE == 2;
+  // (Form C, measured and removed: ONLY waves 0-3 -- which win every issue arbitration against their SIMD partners 4-7 and then idle ~680 cycles at the step's
+  //  barrier -- issue the in-loop requests, two row groups each: QKV 1.069 vs 1.077 ms, out-projection 0.411 vs 0.409, fc1 1.509 vs 1.478, fc2 1.307 vs 1.297 against
+  //  form B: the cost of a request is not the issuing wave's own stall.)
   // (Round-5 experiment forms of the RING3 loop, measured on the fc1 shape and removed: no s_setprio toggles around the MFMA groups 1.488 ms, no toggles + a static
   //  priority for waves 4-7 -- the arbitration losers of every SIMD, the critical path of the step -- 1.500, half 0's fragment reads three per group in groups 0-3
   //  1.509, both 1.500, against 1.497 ms for this loop: nothing.)
@@ -500,18 +500,6 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // ~3 450 cycles per step in the vmcnt wait, and half 1 with its 8 requests took 1 600-2 000 cycles against 770-960 for half 0).
   auto a_slot = [&](int buf) -> half_t* { return RING3 ? lds + buf * TILE256 : lds + buf * (2 * TILE256); };
   auto w_slot = [&](int bufw) -> half_t* { return RING3 ? lds + 3 * TILE256 : lds + bufw * (2 * TILE256) + TILE256; };
-  // (LOADER03: stage_two(…, g, second) stages for wave + 4 * second: the row group 32 rows further down the same 64-row block)
-  auto stage_two = [&](int buf, int bufw, unsigned ta, unsigned tw, int g, int second) {
-    half_t* At = a_slot(buf);
-    half_t* Wt = w_slot(bufw);
-    const int i = g >> 1;
-    unsigned so = ((g & 1) == 0) ? ta + i * sa64 + second * (sa64 >> 1) : tw + i * sw64 + second * (sw64 >> 1);
-    asm volatile("" : "+s"(so));
-    if ((g & 1) == 0)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (WCA_LDS void*)(At + (i * 64 + (wave + 4 * second) * 8) * 64), 16, (int)(va + so), 0, 0, 0);
-    else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + (wave + 4 * second) * 8) * 64), 16, (int)(vw + so), 0, 0, 0);
-  };
   auto stage_one = [&](int buf, int bufw, unsigned ta, unsigned tw, int g) {
     half_t* At = a_slot(buf);
     half_t* Wt = w_slot(bufw);
@@ -730,17 +718,13 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         }
         // RING3: the A tile of step kt + 2 goes out HERE, in half 0 (the two-slot ring cannot: its target slot is still being read), one request in every
         // second group; half 1 keeps only the W requests of the even steps -- at most 4 DMA requests per half instead of 8 in half 1
-        if (LOADER03) {
-          if (wave < 4 && more2) stage_two(prv, 0, ka, kw, 2 * (g >> 1), g & 1);   // A piece g >> 1 for this wave's row group (even g) and for wave + 4's (odd g)
-        } else if (RING3 && (g & 1) == 0 && more2) stage_one(prv, 0, ka, kw, g);
+        if (RING3 && (g & 1) == 0 && more2) stage_one(prv, 0, ka, kw, g);
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(1);
       // all ds_reads of slot `cur` are retired; K step s+1 has landed. Two-slot rings: it is the only DMA in flight. RING3: the 4 youngest requests are
       // the A tile of step s+2 just requested in half 0 (younger than the W requests of the previous step's half 1) and stay in flight across the barrier.
-      if (LOADER03 && wave < 4 && more2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-      else if (LOADER03) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else if (RING3 && more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (RING3 && more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
@@ -767,9 +751,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
           // slower: the 4 W requests in groups 4-7 -- fc1 -0.4 % instead of -2.9 % against the two-slot rings; two of the odd steps' A requests moved from half 0
           // into their request-free half 1 -- every shape SLOWER than the two-slot rings: a request right behind the barrier, where all eight waves issue at the
           // same instant, costs far more than one in half 0, where the SIMD partners are ~400 cycles apart.)
-          if (LOADER03) {
-            if (W_FRESH && wave < 4 && more2) stage_two(cur, 0, ka, kw, 2 * (g >> 1) + 1, g & 1);
-          } else if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);
+          if (W_FRESH && (g & 1) == 1 && more2) stage_one(cur, 0, ka, kw, g);
         } else if (more2 && (W_FRESH || (g & 1) == 0)) {
           stage_one(cur, wslot_2, ka, kw, g);
         }
@@ -1003,7 +985,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   }
   if (a.cu_limit > 0 && a.cu_limit < n_cu) n_cu = a.cu_limit;   // a CU-masked stream: one persistent workgroup per CU it owns
   // pair operands on the persistent kernel: three A slots + one W slot (round 5); the switch gemm_ring = 1 keeps round 4's two-slot rings (A/B, tests)
-  const int ring = splitw ? (debug_switch(DBG_GEMM_RING) == 1 ? 1 : debug_switch(DBG_GEMM_RING) == 3 ? 3 : 2) : 0;
+  const int ring = splitw ? (debug_switch(DBG_GEMM_RING) == 1 ? 1 : 2) : 0;
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
@@ -1078,7 +1060,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
     if (pipelined && splitw && ring == 1) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 1); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 1); } \
-    else if (pipelined && splitw && ring == 3) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 3); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 3); } \
     else if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 2); else if ((S) == 3) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 3, 2); else if ((S) == 2) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 2, 2); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 2); } \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
@@ -1107,9 +1088,6 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
       if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 1);
       else if (a.out_mode == 4) WCA_LAUNCH_DIAG(4, false, 1);
       else if (a.out_mode == 2 && !a.gelu) WCA_LAUNCH_DIAG(2, false, 1);
-      else return hipErrorInvalidValue;
-    } else if (splitw && ring == 3) {
-      if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 3);
       else return hipErrorInvalidValue;
     } else if (splitw) {
       if (a.out_mode == 4 && a.gelu) WCA_LAUNCH_DIAG(4, true, 2);
