@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void attn_split32_kernel(AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt (requested one tile ago) have landed
     __builtin_amdgcn_s_barrier();                      // ... everyone's; and every wave is done with the other slot
     asm volatile("" ::: "memory");
-    if (kt + 1 < nkt) stage(SLOT ^ 1, kt + 1);
+    if (kt + 1 < nkt) stage(SLOT ^ 1, kt + 1);   // (round 5: requested behind the S^T MFMAs instead 1.642 vs 1.648 ms, behind the first P.V block 1.671: nothing)
 
     // ---- S^T: st[kb][r] = s'(q = l31, key = 64 kt + 32 kb + (r&3) + 8 (r>>2) + 4 hh) - m_running; per k step the small terms first
     f32x16 st[2];
