@@ -52,16 +52,13 @@ def main():
         bias = torch.randn(n, device="cuda")
         out = torch.zeros(M, 2 * n, device="cuda", dtype=torch.float16) if mode == 4 else torch.zeros(M, n, device="cuda", dtype=torch.float32)
         mode16 = 0 if mode == 4 else mode
-        t = {"f16": [], "f16 two-slot rings (r1-r4)": [], "k-doubled": [], "splitw": [], "splitw two-slot rings (r4)": [], "splitw 3A+1W (form B)": []}
+        t = {"f16": [], "k-doubled": [], "splitw": [], "splitw two-slot rings (r4)": []}
         for _ in range(reps):
             t["f16"].append(timeit(lambda: chk(lib.wca_test_gemm(eng._h, vp(hi), vp(w), vp(bias), vp(out), M, n, k, gelu, mode16))))
             t["k-doubled"].append(timeit(lambda: chk(lib.wca_test_gemm(eng._h, vp(a2), vp(w2), vp(bias), vp(out), M, n, 2 * k, gelu, mode))))
             t["splitw"].append(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(a2), vp(w), vp(bias), vp(out), M, n, k, gelu, mode))))
             chk(lib.wca_test_set_switch(b"gemm_ring", 1))
-            t["f16 two-slot rings (r1-r4)"].append(timeit(lambda: chk(lib.wca_test_gemm(eng._h, vp(hi), vp(w), vp(bias), vp(out), M, n, k, gelu, mode16))))
             t["splitw two-slot rings (r4)"].append(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(a2), vp(w), vp(bias), vp(out), M, n, k, gelu, mode))))
-            chk(lib.wca_test_set_switch(b"gemm_ring", 2))
-            t["splitw 3A+1W (form B)"].append(timeit(lambda: chk(lib.wca_test_gemm_pairs(eng._h, vp(a2), vp(w), vp(bias), vp(out), M, n, k, gelu, mode))))
             chk(lib.wca_test_set_switch(b"gemm_ring", 0))
         fl = 2.0 * M * n * k
         print("gemm %-4s M=%d N=%d K=%d  " % (name, M, n, k) + "  ".join("%s %.3f ms (%.0f TF alg)" % (kk, min(v), fl / min(v) / 1e9) for kk, v in t.items()), flush=True)

@@ -438,12 +438,12 @@ struct GemmIntC {
 template <int OUT_MODE, bool GELU, int SITE, int STAMP = 0, int SPLITW_MODE = 0>
 __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // SPLITW_MODE: 0 single f16 operands; 1 pair operands, two-slot rings for A and W (round 4); 2 pair operands, THREE A slots + ONE W slot (round 5, below)
-  // 3 pair operands, three A slots + TWO W slots (all 160 KiB; the tile's bias in a register, epilogue_wide<BIAS_REG>): every request in half 0;
-  // 4 single f16 operands, three A slots + two W slots: the A requests in half 0, the W requests in half 1
-  constexpr bool SPLITW = SPLITW_MODE >= 1 && SPLITW_MODE <= 3;
-  constexpr bool RING3 = SPLITW_MODE >= 2;
-  constexpr bool W2 = SPLITW_MODE == 3 || SPLITW_MODE == 4;     // two W slots behind the three A slots
-  constexpr bool BIAS_REG = W2;
+  constexpr bool SPLITW = SPLITW_MODE != 0;
+  constexpr bool RING3 = SPLITW_MODE == 2;
+  // (Forms with TWO W slots behind the three A slots -- all 160 KiB of LDS, the tile's bias in ONE register fetched by ds_bpermute_b32 in the epilogue -- measured and
+  //  removed: pair operands with every request in half 0 (6 + 6 per two steps): QKV 1.141 vs 1.112 ms, fc1 1.584 vs 1.552, fc2 1.405 vs 1.338 against this form -- six
+  //  requests in one half cost more than 4 + 4 + 4; single f16 operands with the A requests in half 0 and the W requests in half 1: QKV -1.2 %, out-projection -5.7 %, fc1
+  //  -1.3 %, fc2 -1.5 % against the two-slot rings, bit-identical -- real, but the f16 mode is the secondary operating point and the form doubles the instantiations.)
   // (Form C, measured and removed: ONLY waves 0-3 -- which win every issue arbitration against their SIMD partners 4-7 and then idle ~680 cycles at the step's
   //  barrier -- issue the in-loop requests, two row groups each: QKV 1.069 vs 1.077 ms, out-projection 0.411 vs 0.409, fc1 1.509 vs 1.478, fc2 1.307 vs 1.297 against
   //  form B: the cost of a request is not the issuing wave's own stall.)
@@ -503,14 +503,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
   // both halves (4 + 4 instead of 0 + 8) and get 1.3 steps of latency cover instead of 0.5-1 (profiles/r05_gemm_stamps.txt: every wave spent ~360 of
   // ~3 450 cycles per step in the vmcnt wait, and half 1 with its 8 requests took 1 600-2 000 cycles against 770-960 for half 0).
   auto a_slot = [&](int buf) -> half_t* { return RING3 ? lds + buf * TILE256 : lds + buf * (2 * TILE256); };
-  auto w_slot = [&](int bufw) -> half_t* { return W2 ? lds + (3 + bufw) * TILE256 : RING3 ? lds + 3 * TILE256 : lds + bufw * (2 * TILE256) + TILE256; };
-  // one W request with a run-time piece index (W2 pair form: which half of a W tile goes out depends on the step's parity)
-  auto stage_w = [&](int bufw, unsigned tw, int piece) {
-    half_t* Wt = w_slot(bufw);
-    unsigned so = tw + piece * sw64;
-    asm volatile("" : "+s"(so));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (piece * 64 + wave * 8) * 64), 16, (int)(vw + so), 0, 0, 0);
-  };
+  auto w_slot = [&](int bufw) -> half_t* { return RING3 ? lds + 3 * TILE256 : lds + bufw * (2 * TILE256) + TILE256; };
   auto stage_one = [&](int buf, int bufw, unsigned ta, unsigned tw, int g) {
     half_t* At = a_slot(buf);
     half_t* Wt = w_slot(bufw);
@@ -525,24 +518,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (WCA_LDS void*)(Wt + (i * 64 + wave * 8) * 64), 16, (int)(vw + so), 0, 0, 0);
   };
 
-  // BIAS_REG: lane l of every wave loads bias[ncol0 + wc * 64 + l] (zero past N / without a bias: the descriptor's range check) into ONE register by an
-  // inline-asm buffer load -- the compiler never waits for it; it is the OLDEST vector-memory operation of its tile, so the first counted vmcnt of the K loop
-  // retires it long before the epilogue reads it
-  typedef int rsrc_words_t __attribute__((ext_vector_type(4)));
-  int bias_bits = 0;
-  auto load_bias_reg = [&](int ncol0) {
-    if (BIAS_REG) {
-      const unsigned long long bp = (unsigned long long)(uintptr_t)a.bias;
-      rsrc_words_t rs = {(int)(unsigned)bp, (int)(unsigned)(bp >> 32), a.bias != nullptr ? a.N * 4 : 0, 0x00020000};
-      const int off = (ncol0 + wc * 64 + lane) * 4;
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(bias_bits) : "v"(off), "s"(rs) : "memory");
-    }
-  };
   auto stage_bias = [&](int par, int ncol0) {
-    if (BIAS_REG) {
-      load_bias_reg(ncol0);
-      return;
-    }
     if (wave < 4) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (WCA_LDS void*)(bias_lds + par * 256 + wave * 64), 4, (ncol0 + wave * 64 + lane) * 4, 0, 0, 0);
       if (OUT_MODE == 3) {
@@ -665,11 +641,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
 #pragma unroll
     for (int g = 0; g < 8; ++g)
       if (!SPLITW || (g & 1) == 0) stage_one(1, 1, ta + a_koff(1), tw + w_koff(1), g);  // SPLITW: step 1 multiplies the W tile of step 0
-    if (W2 && SPLITW) {   // the first half of the W tile of steps 2 / 3 (its second half goes out in step 0)
-      stage_w(1, tw + w_koff(2), 0);
-      stage_w(1, tw + w_koff(2), 1);
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    } else if (SPLITW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (SPLITW) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -716,8 +688,8 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       constexpr int PAR = decltype(par_c)::value;
       const int cur = RING3 ? ring_a : (PAR >= 0 ? PAR : (kt & 1));
       const int nxt = RING3 ? (ring_a == 2 ? 0 : ring_a + 1) : (cur ^ 1);   // A slot of step kt + 1
-      const int wslot = SPLITW ? ((kt >> 1) & 1) : (RING3 ? (kt & 1) : cur);                  // W ring slot of this step (one W slot: w_slot() ignores it)
-      const int wslot_n = SPLITW ? (((kt + 1) >> 1) & 1) : (RING3 ? ((kt + 1) & 1) : (cur ^ 1));   // ... of step kt + 1
+      const int wslot = SPLITW ? ((kt >> 1) & 1) : cur;                 // W ring slot of this step (RING3: one slot, w_slot() ignores it)
+      const int wslot_n = SPLITW ? (((kt + 1) >> 1) & 1) : (cur ^ 1);   // ... of step kt + 1
       // this step's W fragments are new (SPLITW, odd step: those of the step before); wave-uniform
       const bool W_FRESH = !SPLITW || (PAR >= 0 ? PAR == 0 : (kt & 1) == 0);
       const bool W_NEXT_FRESH = !SPLITW || (PAR >= 0 ? PAR == 1 : (kt & 1) == 1);
@@ -729,14 +701,6 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       const unsigned ka = (in_tile2 ? ta + a_koff(kt + 2) : tan + a_koff(kt + 2 - nk));
       const unsigned kw = (in_tile2 ? tw + w_koff(kt + 2) : twn + w_koff(kt + 2 - nk));
       const int prv = RING3 ? (ring_a == 0 ? 2 : ring_a - 1) : 0;   // RING3: the A slot of step kt - 1 = of step kt + 2 (every wave is past that step's barrier)
-      // W2 pair form: half a W tile per step, all in half 0 -- odd steps the first half (pieces 0, 1) of the W tile of steps kt + 3 / kt + 4, even steps the
-      // second half (pieces 2, 3) of the W tile of steps kt + 2 / kt + 3; its slot (k' & 1) last held the W tile of two tiles back, dead since step kt - 1's barrier
-      const int wt = kt + ((kt & 1) ? 3 : 2);
-      const bool w_in = wt < nk;
-      const bool w_more = W2 && SPLITW && (w_in || has_next);
-      const unsigned kwt = w_in ? tw + w_koff(wt) : twn + w_koff(wt - nk);
-      const int wt_slot = ((w_in ? wt : wt - nk) >> 1) & 1;
-      const int wt_piece = (kt & 1) ? 0 : 2;
       WCA_STAMP(0);
       // ---- K half 0 (fragments w0/x0 were fetched under the previous step's half 1). The 12 fragment reads of
       // half 1 are issued two at a time between groups of 4 MFMAs.
@@ -759,17 +723,12 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         // RING3: the A tile of step kt + 2 goes out HERE, in half 0 (the two-slot ring cannot: its target slot is still being read), one request in every
         // second group; half 1 keeps only the W requests of the even steps -- at most 4 DMA requests per half instead of 8 in half 1
         if (RING3 && (g & 1) == 0 && more2) stage_one(prv, 0, ka, kw, g);
-        if (W2 && SPLITW && w_more) {
-          if (g == 1) stage_w(wt_slot, kwt, wt_piece);
-          if (g == 5) stage_w(wt_slot, kwt, wt_piece + 1);
-        }
         __builtin_amdgcn_sched_barrier(0);
       }
       WCA_STAMP(1);
       // all ds_reads of slot `cur` are retired; K step s+1 has landed. Two-slot rings: it is the only DMA in flight. RING3: the 4 youngest requests are
       // the A tile of step s+2 just requested in half 0 (younger than the W requests of the previous step's half 1) and stay in flight across the barrier.
-      if (W2 && SPLITW && more2 && w_more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-      else if (RING3 && more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      if (RING3 && more2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       WCA_STAMP(2);
       __builtin_amdgcn_s_barrier();
@@ -781,7 +740,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
       // issue last (measured with s_memtime stamps: ~1000 cycles of barrier skew per K tile).
       // SPLITW: the W tile of step s+2 is new only when s is even (it goes to the W slot that step s-1 read last: every wave is
       // past that step's barrier), and the next step's W fragments are re-fetched only when s is odd.
-      const int wslot_2 = SPLITW ? (wslot ^ 1) : (RING3 ? (kt & 1) : cur);   // W ring slot of step kt + 2
+      const int wslot_2 = SPLITW ? (wslot ^ 1) : cur;   // W ring slot of step kt + 2
       const half_t* An = a_slot(nxt);
       const half_t* Wn = w_slot(wslot_n);
 #pragma unroll
@@ -791,11 +750,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         for (int nt = 0; nt < 4; ++nt) acc[g][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[nt], x1[g], acc[g][nt], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
-        if (W2 && SPLITW) {
-          // (every request of this form went out in half 0)
-        } else if (W2) {
-          if ((g & 1) == 1 && more2) stage_one(cur, wslot_2, ka, kw, g);   // f16 operands: the W tile of step kt + 2 into the slot this step's W tile just left
-        } else if (RING3) {
+        if (RING3) {
           // the W tile of step kt + 2 into the one W slot (dead since this step's barrier), one request in every second group. (Measured alternatives, both
           // slower: the 4 W requests in groups 4-7 -- fc1 -0.4 % instead of -2.9 % against the two-slot rings; two of the odd steps' A requests moved from half 0
           // into their request-free half 1 -- every shape SLOWER than the two-slot rings: a request right behind the barrier, where all eight waves issue at the
@@ -840,7 +795,7 @@ __global__ __launch_bounds__(512) void gemm256p_f16_kernel(GemmArgs a) {
         epilogue_ln<KernArgs>(*ap, acc, m0, m0 >> 8, n0 >> 8, ntn, wr, wc, fr_e, fg_e, bias_lds + par * 256 + wc * 64, gamma_lds + par * 256,
                               beta_lds + par * 256, ln_lds);
       else
-        epilogue_wide<OUT_MODE, GELU, KernArgs, BIAS_REG>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64, bias_bits);
+        epilogue_wide<OUT_MODE, GELU, KernArgs>(*ap, acc, m0 + wr * 128, n0 + wc * 64, fr_e, fg_e, bias_lds + par * 256 + wc * 64);
     }
     if (STAMP == 1 && lane == 0 && blockIdx.x < 4 && (v / G) < 12)
       a.dbg[((blockIdx.x * 8 + wave) * 64 + 48 + v / G) * 8 + 1] = __builtin_readcyclecounter();
@@ -1034,11 +989,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   }
   if (a.cu_limit > 0 && a.cu_limit < n_cu) n_cu = a.cu_limit;   // a CU-masked stream: one persistent workgroup per CU it owns
   // pair operands on the persistent kernel: three A slots + one W slot (round 5); the switch gemm_ring = 1 keeps round 4's two-slot rings (A/B, tests)
-  // LDS ring form of the persistent kernel (gemm256p_f16_kernel's SPLITW_MODE). Default: pair operands 3 (three A slots + two W slots, every request in half 0), single
-  // f16 operands 4 (three A slots + two W slots); the switch gemm_ring = 1 keeps the two-slot rings of rounds 1-4 for both, 2 = round 5's first pair form (three A slots +
-  // ONE W slot) and the two-slot f16 form -- A/B and bit-identity tests
-  const int ring_sw = debug_switch(DBG_GEMM_RING);
-  const int ring = splitw ? (ring_sw == 1 ? 1 : ring_sw == 2 ? 2 : 3) : ((ring_sw == 1 || ring_sw == 2 || a.out_mode == 3 || a.dbg != nullptr || a.dbg_wrap_m > 0) ? 0 : 4);
+  const int ring = splitw ? (debug_switch(DBG_GEMM_RING) == 1 ? 1 : 2) : 0;
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
   const bool pipelined = want_big && can_buf && a.force_tile != 256;
   const bool big = want_big;
@@ -1050,8 +1001,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
     block = dim3(512);
     shmem = 2 * 2 * 256 * 64 * sizeof(half_t);  // 128 KiB
     if (pipelined) {
-      if (ring == 3 || ring == 4) shmem = 5 * 256 * 64 * sizeof(half_t);   // three A slots + two W slots = all 160 KiB of the CU's LDS (the bias travels in a register)
-      else shmem += 2 * 256 * sizeof(float);  // the tile's bias values, double buffered
+      shmem += 2 * 256 * sizeof(float);  // the tile's bias values, double buffered
       // persistent: one workgroup per CU walks tiles blockIdx.x, + gridDim.x, ... (the ring-slot parity carries
       // over a tile boundary only for an even number of K tiles); force_tile 258 = one tile per workgroup
       const int nk = (splitw ? 2 : 1) * (a.K / BK);
@@ -1114,9 +1064,7 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
 #define WCA_LAUNCH_S(OM, G, S)                            \
   do {                                                    \
     if (pipelined && splitw && ring == 1) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 1); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 1); } \
-    else if (pipelined && splitw && ring == 2) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 2); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 2); } \
-    else if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 3); else if ((S) == 3) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 3, 3); else if ((S) == 2) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 2, 3); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 3); } \
-    else if (pipelined && ring == 4) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 4); else if ((S) == 3) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 3, 4); else if ((S) == 2) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 2, 4); else if ((S) == 1) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 4); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 0, 4); } \
+    else if (pipelined && splitw) { if ((S) == 4) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 4, 2); else if ((S) == 3) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 3, 2); else if ((S) == 2) WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 2, 2); else WCA_LAUNCH_K5R(gemm256p_f16_kernel, OM, G, 1, 2); } \
     else if (pipelined) WCA_LAUNCH_K(gemm256p_f16_kernel, OM, G, S); \
     else if (big) WCA_LAUNCH_K(gemm256_f16_kernel, OM, G, S);  \
     else WCA_LAUNCH_K(gemm_f16_kernel, OM, G, S);         \

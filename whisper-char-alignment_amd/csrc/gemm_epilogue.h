@@ -11,10 +11,8 @@ namespace wca {
 
 // ArgsT: GemmArgs, or GemmArgs in the constant address space (the kernarg segment: fields are then re-read with
 // scalar loads where they are used instead of staying live in SGPRs across the caller's K loop).
-// BIAS_REG: the wave's 64 bias values live in ONE VGPR (lane l holds bias[nbase + l], bias_bits) and each lane fetches its 16 by ds_bpermute_b32 -- no LDS
-// memory (the ring forms that use all 160 KiB of the CU's LDS for operand tiles)
-template <int OUT_MODE, bool GELU, typename ArgsT, bool BIAS_REG = false>
-__device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg, const float* bias_l, int bias_bits = 0) {
+template <int OUT_MODE, bool GELU, typename ArgsT>
+__device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4], int mbase, int nbase, int fr, int fg, const float* bias_l) {
   // column of value (nt, r = 0) relative to nbase
   int col[4];
 #pragma unroll
@@ -23,14 +21,9 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
   float bv[16];
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    if (BIAS_REG) {
+    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + col[nt]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt * 4 + r] = __int_as_float(__builtin_amdgcn_ds_bpermute((col[nt] + r) * 4, bias_bits));
-    } else {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + col[nt]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[nt * 4 + r] = b4[r];
-    }
+    for (int r = 0; r < 4; ++r) bv[nt * 4 + r] = b4[r];
   }
   const bool full_n = (nbase + 64 <= a.N);
   if (OUT_MODE == 2) {
