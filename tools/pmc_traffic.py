@@ -28,21 +28,21 @@ def per_launch(d, counter, needle):
 
 
 SITES = {  # site -> (kernel-name substring, lambda(M, d) -> (N, K), read-modify-write f32 residual?)
-    "qkv": ("gemm256p_f16_kernel<0, false, 1, false>", lambda d: (3 * d, d), False),
-    "out_proj": ("gemm256p_f16_kernel<3, false, 1, false>", lambda d: (d, d), True),   # round 3: LayerNorm fused (default)
-    "fc1": ("gemm256p_f16_kernel<0, true, 1, false>", lambda d: (4 * d, d), False),
-    "fc2": ("gemm256p_f16_kernel<3, false, 4, false>", lambda d: (d, 4 * d), True),
+    "qkv": ("gemm256p_f16_kernel<0, false, 1, 0, 0>", lambda d: (3 * d, d), False),
+    "out_proj": ("gemm256p_f16_kernel<3, false, 1, 0, 0>", lambda d: (d, d), True),   # round 3: LayerNorm fused (default)
+    "fc1": ("gemm256p_f16_kernel<0, true, 1, 0, 0>", lambda d: (4 * d, d), False),
+    "fc2": ("gemm256p_f16_kernel<3, false, 4, 0, 0>", lambda d: (d, 4 * d), True),
     "attention": ("attn32_kernel<false>", None, False),
 }
 
 
 # the pair-operand kernels of the reference precision mode (WCA_PRECISION=reference): A rows and f16 outputs are (hi, lo) pairs
 SITES_REFERENCE = {
-    "qkv": ("gemm256p_f16_kernel<4, false, 1, false, true>", lambda d: (3 * d, d), False),
-    "out_proj": ("gemm256p_f16_kernel<2, false, 1, false, true>", lambda d: (d, d), True),
-    "fc1": ("gemm256p_f16_kernel<4, true, 1, false, true>", lambda d: (4 * d, d), False),
-    "fc2": ("gemm256p_f16_kernel<2, false, 4, false, true>", lambda d: (d, 4 * d), True),
-    "attention": ("attn_split32_kernel", None, False),
+    "qkv": ("gemm256p_f16_kernel<4, false, 1, 0, 2>", lambda d: (3 * d, d), False),
+    "out_proj": ("gemm256p_f16_kernel<2, false, 1, 0, 2>", lambda d: (d, d), True),
+    "fc1": ("gemm256p_f16_kernel<4, true, 1, 0, 2>", lambda d: (4 * d, d), False),
+    "fc2": ("gemm256p_f16_kernel<2, false, 4, 0, 2>", lambda d: (d, 4 * d), True),
+    "attention": ("attn_split32_kernel<0>", None, False),
 }
 
 
