@@ -60,3 +60,19 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), "%s imports the oracle" % f
                 assert "liboracle" not in text
+
+
+def test_switch_table_is_host_side_and_rejects_unknown_names(wca):
+    """The A/B / test switches of the library (csrc/debug_switch.cpp, wca_test_set_switch: ADVICE r4 -- no environment variable is read per launch any more) and
+    the round-5 null-argument paths, none of which needs a GPU."""
+    lib = wca._lib.load()
+    for name in (b"attn_split_variant", b"attn_variant", b"head_stats_general", b"gemm_supertile", b"ln_pair_v4", b"fail_precision_alloc", b"attn_split_drop",
+                 b"gemm_ring"):
+        assert lib.wca_test_set_switch(name, 1) == 0 and lib.wca_test_set_switch(name, 0) == 0
+    assert lib.wca_test_set_switch(b"no_such_switch", 1) < 0 and b"unknown switch" in lib.wca_last_error()
+    assert lib.wca_test_set_switch(None, 1) < 0
+    assert lib.wca_test_set_attn_split_drop(5) < 0 and lib.wca_test_set_attn_split_drop(9) == 0 and lib.wca_test_set_attn_split_drop(0) == 0
+    assert lib.wca_weights_inexact(None, None, None, None, 0) < 0 and lib.wca_set_allow_rounded_weights(None, 1) < 0
+    # the library reads no environment variable on a launch path: the remaining getenv calls are one-time initialisers
+    for f in ("gemm.hip", "attention.hip", "attention_split.hip", "postproc.hip", "elementwise.hip", "gemm_rows.hip", "dtw.hip", "logmel.hip", "decode.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "whisper-char-alignment_amd", "csrc", f)).read(), f
