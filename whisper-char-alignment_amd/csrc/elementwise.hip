@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void layernorm_f16_v2_kernel(const float* __re
 // embedding table: the row is embedded as token 0 and *err is raised; the host reports WCA_ERR_INVALID at its next sync.
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tokens, const half_t* __restrict__ tok_emb,
                                                     const float* __restrict__ pos_emb, float* __restrict__ x, int B, int n,
-                                                    int d, int n_vocab, int* __restrict__ err) {
+                                                    int d, int n_vocab, int* __restrict__ err, const half_t* __restrict__ tok_emb_lo) {
   const int row = blockIdx.x;  // b*n + i
   const int i = row % n;
   long tok = tokens[row];
@@ -196,6 +196,11 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
   const half_t* e = tok_emb + tok * d;
   const float* p = pos_emb + (long)i * d;
   float* o = x + (long)row * d;
+  if (tok_emb_lo != nullptr) {   // an embedding table that is not exact in f16: value = hi + lo (engine.hip, W_lo slab)
+    const half_t* el = tok_emb_lo + tok * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) o[c] = ((float)e[c] + (float)el[c]) + p[c];
+    return;
+  }
   for (int c = threadIdx.x; c < d; c += blockDim.x) o[c] = (float)e[c] + p[c];
 }
 
@@ -251,9 +256,9 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
 }
 
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x, int B, int n,
-                        int d, int n_vocab, int* err, hipStream_t s) {
+                        int d, int n_vocab, int* err, hipStream_t s, const half_t* tok_emb_lo) {
   if (B * n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(embed_kernel, dim3(B * n), dim3(256), 0, s, tokens, tok_emb, pos_emb, x, B, n, d, n_vocab, err);
+  hipLaunchKernelGGL(embed_kernel, dim3(B * n), dim3(256), 0, s, tokens, tok_emb, pos_emb, x, B, n, d, n_vocab, err, tok_emb_lo);
   return hipGetLastError();
 }
 

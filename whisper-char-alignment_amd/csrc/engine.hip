@@ -133,7 +133,12 @@ struct wca_engine {
   bool profiling = false;
   std::set<std::string> loaded;
   std::map<std::string, size_t> inexact;  // tensors stored as f16 whose fp32 source values were NOT f16-representable: name -> count of rounded elements
-  bool allow_rounded = false;             // wca_set_allow_rounded_weights: run pair sites on such (rounded) weights although that is not the reference's arithmetic
+  bool allow_rounded = false;             // wca_set_allow_rounded_weights: run pair sites on the ROUNDED weights (faster; not the fp32 model's arithmetic)
+  char* wslab_lo = nullptr;               // W_lo slab, same layout as wslab (allocated when the first inexact tensor arrives): lo = f16(w - f16(w)) of every
+                                          // weight matrix element, zero where the f16 value is exact. A pair site multiplies the extra term A_hi W_lo^T
+  std::set<const void*> wlo_bases;        // weight matrices (base pointer the GEMM call sites use) that hold at least one non-zero lo element
+  GrowBuf wlo_tmp[2];                     // f32 [M][N] scratch of the extra term for the non-accumulating output modes: [0] launches on `stream` (phase 1),
+                                          // [1] on any other stream (phase 2 runs beside the next batch's phase 1)
 
   // ---- weights
   char* wslab = nullptr;
@@ -225,6 +230,7 @@ struct wca_engine {
   bool sw_dirty = true;      // a weight was (re)loaded since the copies were built
   struct SplitW {
     half_t *conv1_w = nullptr, *conv2_w = nullptr, *kv_w = nullptr, *tok_emb = nullptr;
+    half_t *conv1_wlo = nullptr, *conv2_wlo = nullptr;   // [W_lo | 0] per tap group: the conv stem's extra term against [hi(C) | lo(C)] frames (inexact conv weights)
     int k1pad = 0;           // padded K of the split conv1 GEMM: windows of 3 frames x [hi(C) | lo(C)]
     std::vector<LayerW> enc, dec;  // only the half_t* members are used
   } sw;
@@ -260,6 +266,12 @@ T* carve(char*& cur, size_t count, size_t align = 256) {
   return r;
 }
 
+// ---- weights that are not exact in f16 (fp32 checkpoints): the W_lo slab mirrors wslab byte for byte
+inline bool use_wlo(const wca_engine* e) { return e->wslab_lo != nullptr && !e->wlo_bases.empty() && !e->allow_rounded; }
+inline const half_t* wlo_of(const wca_engine* e, const half_t* w) {
+  return reinterpret_cast<const half_t*>(e->wslab_lo + (reinterpret_cast<const char*>(w) - e->wslab));
+}
+
 // ---- per-site precision (wca_set_precision_sites): which stages compute on (hi, lo) operand pairs
 inline bool site_on(const wca_engine* e, unsigned bit) { return (e->sites & bit) != 0; }
 inline bool enc_gemm_split(const wca_engine* e, int li) { return (e->sites & WCA_PSITE_ENC_GEMM) && li >= e->enc_from && li < e->dims.n_audio_layer; }
@@ -274,11 +286,13 @@ struct GemmOpnd {
   const half_t* W;
   int lda, K, ldw;
   long a_lo;
+  const half_t* Wp;   // the plain [N][K] matrix when the product is a PAIR product (null otherwise): where the W_lo term of an inexact matrix comes from
+  int Kp;
 };
 inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K, int M = 0, int N = 0, int out_mode = 0) {
   const bool use = a_pair && want;
-  if (use && M > 0 && gemm_splitw_supported(M, N, K, 2 * K, out_mode)) return GemmOpnd{W1, 2 * K, K, K, (long)K};
-  return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K, 0};
+  if (use && M > 0 && gemm_splitw_supported(M, N, K, 2 * K, out_mode)) return GemmOpnd{W1, 2 * K, K, K, (long)K, W1, K};
+  return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K, 0, use ? W1 : nullptr, K};
 }
 
 // ---- weight slab layout (two passes: size, then carve)
@@ -401,6 +415,8 @@ size_t layout_split_weights(wca_engine* e, char* base) {
   e->sw.k1pad = (int)align_up((size_t)6 * D.n_mels, 64);
   e->sw.conv1_w = carve<half_t>(cur, d * e->sw.k1pad);
   e->sw.conv2_w = carve<half_t>(cur, d * 6 * d);
+  e->sw.conv1_wlo = carve<half_t>(cur, d * e->sw.k1pad);
+  e->sw.conv2_wlo = carve<half_t>(cur, d * 6 * d);
   e->sw.enc.assign(D.n_audio_layer, LayerW{});
   for (auto& l : e->sw.enc) {
     l.qkv_w = carve<half_t>(cur, 3 * d * 2 * d);
@@ -425,7 +441,8 @@ size_t layout_split_weights(wca_engine* e, char* base) {
 // dst[n][(j / grp) * 2 * grp + (j % grp) + {0, grp}] = src[n][j] for j < K: every group of `grp` source columns is written twice,
 // side by side. grp = K: [W | W] (a Linear weight against [hi(K) | lo(K)] activation rows); grp = channels of a conv input: the
 // taps of the time-major conv GEMM against frames stored as [hi(C) | lo(C)]. Columns of dst past 2 K stay zero.
-__global__ void dup_cols_kernel(const half_t* __restrict__ src, int ld_src, half_t* __restrict__ dst, int ld_dst, long N, int K, int grp) {
+// second_zero: the second copy is zero -- [W_lo | 0]: a remainder matrix against pair rows multiplies the hi halves only
+__global__ void dup_cols_kernel(const half_t* __restrict__ src, int ld_src, half_t* __restrict__ dst, int ld_dst, long N, int K, int grp, int second_zero) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * K) return;
   const long n = i / K;
@@ -434,12 +451,12 @@ __global__ void dup_cols_kernel(const half_t* __restrict__ src, int ld_src, half
   const int g = j / grp, c = j - g * grp;
   half_t* o = dst + n * ld_dst + (long)g * 2 * grp + c;
   o[0] = v;
-  o[grp] = v;
+  o[grp] = second_zero ? (half_t)0.f : v;
 }
 
-int dup_cols(hipStream_t s, const half_t* src, int ld_src, half_t* dst, int ld_dst, long N, int K, int grp) {
+int dup_cols(hipStream_t s, const half_t* src, int ld_src, half_t* dst, int ld_dst, long N, int K, int grp, int second_zero = 0) {
   const long tot = N * K;
-  hipLaunchKernelGGL(dup_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, N, K, grp);
+  hipLaunchKernelGGL(dup_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, ld_src, dst, ld_dst, N, K, grp, second_zero);
   HIPCHK(hipGetLastError());
   return WCA_OK;
 }
@@ -452,6 +469,10 @@ int ensure_split_weights(wca_engine* e) {
   hipStream_t s = e->stream;
   WCA_TRY(dup_cols(s, e->conv1_w, e->k1pad, e->sw.conv1_w, e->sw.k1pad, d, 3 * C, C));
   WCA_TRY(dup_cols(s, e->conv2_w, 3 * d, e->sw.conv2_w, 6 * d, d, 3 * d, d));
+  if (e->wslab_lo) {   // the conv stem's remainder matrices in the layout of its pair GEMM
+    WCA_TRY(dup_cols(s, wlo_of(e, e->conv1_w), e->k1pad, e->sw.conv1_wlo, e->sw.k1pad, d, 3 * C, C, 1));
+    WCA_TRY(dup_cols(s, wlo_of(e, e->conv2_w), 3 * d, e->sw.conv2_wlo, 6 * d, d, 3 * d, d, 1));
+  }
   for (int li = 0; li < D.n_audio_layer; ++li) {
     const LayerW& l = e->enc[li];
     const LayerW& w = e->sw.enc[li];
@@ -481,8 +502,12 @@ int ensure_split_weights(wca_engine* e) {
 // c_lo > 0 (split mode, f16 output): the value is stored as the pair hi at C, lo at C + c_lo (out_mode 4)
 thread_local int g_gemm_cu_limit = 0;  // CUs owned by the stream the current phase launches on (0 = the whole device)
 
+// wlo_e / w_plain / k_plain (pair products only, GemmOpnd::Wp / Kp): when the engine holds a W_lo slab and this matrix has non-zero lo elements (an fp32
+// checkpoint that is not exact in f16), the product gets its third term A_hi W_lo^T -- the A_lo W_lo^T term is below 2^-22 of the result like every dropped
+// lo.lo term: an accumulating launch for the read-modify-write mode, an f32 scratch added before the activation (GemmArgs.addend) for the others.
 hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, void* C, int ldc, int M,
-                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0, long a_lo = 0) {
+                int N, int K, int gelu, int out_mode, int site = 0, float* sk_ws = nullptr, size_t sk_bytes = 0, long c_lo = 0, long a_lo = 0,
+                wca_engine* wlo_e = nullptr, const half_t* w_plain = nullptr, int k_plain = 0) {
   GemmArgs g{};
   g.a_lo = a_lo;
   g.cu_limit = g_gemm_cu_limit;
@@ -503,6 +528,32 @@ hipError_t gemm(hipStream_t s, const half_t* A, int lda, const half_t* W, int ld
   g.gelu = gelu;
   g.out_mode = out_mode;
   g.site = site;
+  if (wlo_e != nullptr && w_plain != nullptr && use_wlo(wlo_e) && wlo_e->wlo_bases.count(w_plain)) {
+    GemmArgs x{};   // A_hi (the hi halves of the pair rows: same row stride, k_plain columns) x W_lo^T (plain [N][k_plain])
+    x.cu_limit = g_gemm_cu_limit;
+    x.A = A;
+    x.lda = lda;
+    x.W = wlo_of(wlo_e, w_plain);
+    x.ldw = k_plain;
+    x.M = M;
+    x.N = N;
+    x.K = k_plain;
+    x.site = site;
+    if (out_mode == 2) {
+      x.C = C;
+      x.ldc = ldc;
+      x.out_mode = 2;
+    } else {
+      GrowBuf& tmp = wlo_e->wlo_tmp[s == wlo_e->stream ? 0 : 1];
+      if (hipError_t he = tmp.ensure((size_t)M * N * sizeof(float)); he != hipSuccess) return he;
+      x.C = tmp.p;
+      x.ldc = N;
+      x.out_mode = 1;
+      g.addend = (const float*)tmp.p;
+      g.ld_addend = N;
+    }
+    if (hipError_t he = launch_gemm(x, s); he != hipSuccess) return he;
+  }
   return launch_gemm(g, s);
 }
 
@@ -565,7 +616,7 @@ int dec_gemm(wca_engine* e, hipStream_t s, int ws, const half_t* A, int lda, con
 // as the GEMM's site alone.
 int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, const half_t* W, int ldw, const float* bias, float* x, int M, int N,
                      int K, const float* gamma, const float* beta, half_t* xn, bool ln_pair, int site, bool allow_fused = true, int ev_gemm_site = -1,
-                     int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0, long a_lo = 0) {
+                     int ev_gemm_li = 0, int ev_ln_site = -1, int ev_ln_li = 0, long a_lo = 0, const half_t* w_plain = nullptr, int k_plain = 0) {
   auto ev = [&](int st, int li, int which) {
     if (e->profiling && st >= 0 && li >= 0 && li < 33) {
       (void)hipEventRecord(e->kev[st][li][which], s);
@@ -600,7 +651,7 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
     ev(ev_gemm_site, ev_gemm_li, 1);
     return WCA_OK;
   }
-  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes, 0, a_lo));
+  HIPCHK(gemm(s, A, lda, W, ldw, bias, x, N, M, N, K, 0, 2, site, e->sk_big[0], e->sk_big_bytes, 0, a_lo, e, w_plain, k_plain));
   ev(ev_gemm_site, ev_gemm_li, 1);
   ev(ev_ln_site, ev_ln_li, 0);
   HIPCHK(launch_layernorm_f16(x, gamma, beta, xn, M, N, 1e-5f, s, om * N, ln_pair ? N : 0));
@@ -610,14 +661,22 @@ int gemm_residual_ln(wca_engine* e, hipStream_t s, const half_t* A, int lda, con
 
 // upload helpers: convert host tensor (f32 or f16) into device f16 / f32
 // Every weight matrix is f16 AT REST here, like every openai checkpoint ("weights stored fp16, loaded into fp32 params",
-// /root/reference/infer_ali.py:36-37), which is what makes A W^T exact-operand arithmetic in the pair mode. An fp32 source whose values
-// are not f16-representable (a fine-tuned fp32 state dict) is ROUNDED here: *n_inexact counts those elements (NaN == NaN for this purpose);
-// wca_load_weight records them per tensor and the pair sites refuse to run on such weights unless the caller opted in (check_ready).
-int put_f16(half_t* dst, const void* src, int dtype, size_t n, size_t* n_inexact) {
+// /root/reference/infer_ali.py:36-37), which is what makes A W^T exact-operand arithmetic in the pair mode. An fp32 source whose values are not
+// f16-representable (a fine-tuned fp32 state dict) keeps its REMAINDER lo = f16(w - f16(w)) in the W_lo slab (same offset as the f16 value in wslab;
+// allocated when the first such tensor arrives), and the pair sites multiply the extra term A_hi W_lo^T (gemm()): w = hi + lo to 2^-22 |w|, the same
+// representation the activations travel in. *n_inexact counts the elements with a non-zero remainder (NaN == NaN for this purpose); `base` is the matrix
+// the GEMM call sites address (a fused matrix holds several tensors).
+int ensure_wlo_slab(wca_engine* e) {
+  if (e->wslab_lo) return WCA_OK;
+  HIPCHK(hipMalloc((void**)&e->wslab_lo, e->wslab_bytes));
+  HIPCHK(hipMemset(e->wslab_lo, 0, e->wslab_bytes));
+  return WCA_OK;
+}
+int put_f16(wca_engine* e, const half_t* base, half_t* dst, const void* src, int dtype, size_t n, size_t* n_inexact) {
   std::vector<half_t> tmp(n);
+  size_t bad = 0;
   if (dtype == WCA_DTYPE_F32) {
     const float* s = static_cast<const float*>(src);
-    size_t bad = 0;
     for (size_t i = 0; i < n; ++i) {
       tmp[i] = (half_t)s[i];
       bad += ((float)tmp[i] != s[i]) && (s[i] == s[i]);
@@ -627,6 +686,20 @@ int put_f16(half_t* dst, const void* src, int dtype, size_t n, size_t* n_inexact
     memcpy(tmp.data(), src, n * sizeof(half_t));
   }
   HIPCHK(hipMemcpy(dst, tmp.data(), n * sizeof(half_t), hipMemcpyHostToDevice));
+  if (bad > 0 || e->wslab_lo) {   // the remainders (zeros when this tensor is exact and replaces an inexact one)
+    if (bad > 0) {
+      WCA_TRY(ensure_wlo_slab(e));
+      const float* s = static_cast<const float*>(src);
+      for (size_t i = 0; i < n; ++i) {
+        const float r = s[i] - (float)tmp[i];
+        tmp[i] = (r == r && std::fabs(r) < 65504.f) ? (half_t)r : (half_t)0.f;
+      }
+      e->wlo_bases.insert(base);
+    } else {
+      std::fill(tmp.begin(), tmp.end(), (half_t)0.f);
+    }
+    HIPCHK(hipMemcpy(e->wslab_lo + (reinterpret_cast<char*>(dst) - e->wslab), tmp.data(), n * sizeof(half_t), hipMemcpyHostToDevice));
+  }
   return WCA_OK;
 }
 int put_f32(float* dst, const void* src, int dtype, size_t n) {
@@ -644,9 +717,9 @@ inline float host_val(const void* src, int dtype, size_t i) {
   return dtype == WCA_DTYPE_F32 ? static_cast<const float*>(src)[i] : (float)static_cast<const half_t*>(src)[i];
 }
 
-// conv weight [out][in][3] -> f16 [out][kpad] with column tap*in + c
-int put_conv(half_t* dst, const void* src, int dtype, int out, int in, int kpad, size_t* n_inexact) {
-  std::vector<half_t> tmp((size_t)out * kpad, (half_t)0.f);
+// conv weight [out][in][3] -> f16 [out][kpad] with column tap*in + c (remainders of inexact fp32 values into the W_lo slab, like put_f16)
+int put_conv(wca_engine* e, half_t* dst, const void* src, int dtype, int out, int in, int kpad, size_t* n_inexact) {
+  std::vector<half_t> tmp((size_t)out * kpad, (half_t)0.f), lo((size_t)out * kpad, (half_t)0.f);
   size_t bad = 0;
   for (int n = 0; n < out; ++n)
     for (int c = 0; c < in; ++c)
@@ -654,10 +727,21 @@ int put_conv(half_t* dst, const void* src, int dtype, int out, int in, int kpad,
         const float v = host_val(src, dtype, ((size_t)n * in + c) * 3 + t);
         const half_t h = (half_t)v;
         tmp[(size_t)n * kpad + t * in + c] = h;
-        bad += ((float)h != v) && (v == v);
+        if ((float)h != v && v == v) {
+          ++bad;
+          const float r = v - (float)h;
+          lo[(size_t)n * kpad + t * in + c] = std::fabs(r) < 65504.f ? (half_t)r : (half_t)0.f;
+        }
       }
   *n_inexact += bad;
   HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  if (bad > 0 || e->wslab_lo) {
+    if (bad > 0) {
+      WCA_TRY(ensure_wlo_slab(e));
+      e->wlo_bases.insert(dst);
+    }
+    HIPCHK(hipMemcpy(e->wslab_lo + (reinterpret_cast<char*>(dst) - e->wslab), lo.data(), lo.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  }
   return WCA_OK;
 }
 
@@ -673,28 +757,28 @@ int load_block_tensor(wca_engine* e, LayerW& l, bool is_dec, int li, const std::
   auto expect = [&](size_t want) -> bool { return n == want; };
 #define WANT(cnt) \
   if (!expect(cnt)) return fail(WCA_ERR_INVALID, "weight %s: expected %zu elements, got %zu", rest.c_str(), (size_t)(cnt), n)
-  if (rest == "attn.query.weight") { WANT(dd); return put_f16(l.qkv_w, p, dtype, n, n_inexact); }
+  if (rest == "attn.query.weight") { WANT(dd); return put_f16(e, l.qkv_w, l.qkv_w, p, dtype, n, n_inexact); }
   if (rest == "attn.query.bias") { WANT(d); return put_f32(l.qkv_b, p, dtype, n); }
-  if (rest == "attn.key.weight") { WANT(dd); return put_f16(l.qkv_w + dd, p, dtype, n, n_inexact); }
-  if (rest == "attn.value.weight") { WANT(dd); return put_f16(l.qkv_w + 2 * dd, p, dtype, n, n_inexact); }
+  if (rest == "attn.key.weight") { WANT(dd); return put_f16(e, l.qkv_w, l.qkv_w + dd, p, dtype, n, n_inexact); }
+  if (rest == "attn.value.weight") { WANT(dd); return put_f16(e, l.qkv_w, l.qkv_w + 2 * dd, p, dtype, n, n_inexact); }
   if (rest == "attn.value.bias") { WANT(d); return put_f32(l.qkv_b + 2 * d, p, dtype, n); }
-  if (rest == "attn.out.weight") { WANT(dd); return put_f16(l.out_w, p, dtype, n, n_inexact); }
+  if (rest == "attn.out.weight") { WANT(dd); return put_f16(e, l.out_w, l.out_w, p, dtype, n, n_inexact); }
   if (rest == "attn.out.bias") { WANT(d); return put_f32(l.out_b, p, dtype, n); }
   if (rest == "attn_ln.weight") { WANT(d); return put_f32(l.ln1_g, p, dtype, n); }
   if (rest == "attn_ln.bias") { WANT(d); return put_f32(l.ln1_b, p, dtype, n); }
-  if (rest == "mlp.0.weight") { WANT(4 * dd); return put_f16(l.fc1_w, p, dtype, n, n_inexact); }
+  if (rest == "mlp.0.weight") { WANT(4 * dd); return put_f16(e, l.fc1_w, l.fc1_w, p, dtype, n, n_inexact); }
   if (rest == "mlp.0.bias") { WANT(4 * (size_t)d); return put_f32(l.fc1_b, p, dtype, n); }
-  if (rest == "mlp.2.weight") { WANT(4 * dd); return put_f16(l.fc2_w, p, dtype, n, n_inexact); }
+  if (rest == "mlp.2.weight") { WANT(4 * dd); return put_f16(e, l.fc2_w, l.fc2_w, p, dtype, n, n_inexact); }
   if (rest == "mlp.2.bias") { WANT(d); return put_f32(l.fc2_b, p, dtype, n); }
   if (rest == "mlp_ln.weight") { WANT(d); return put_f32(l.ln2_g, p, dtype, n); }
   if (rest == "mlp_ln.bias") { WANT(d); return put_f32(l.ln2_b, p, dtype, n); }
   if (is_dec) {
-    if (rest == "cross_attn.query.weight") { WANT(dd); return put_f16(l.cq_w, p, dtype, n, n_inexact); }
+    if (rest == "cross_attn.query.weight") { WANT(dd); return put_f16(e, l.cq_w, l.cq_w, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.query.bias") { WANT(d); return put_f32(l.cq_b, p, dtype, n); }
-    if (rest == "cross_attn.key.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li) * dd, p, dtype, n, n_inexact); }
-    if (rest == "cross_attn.value.weight") { WANT(dd); return put_f16(e->kv_w + (size_t)(2 * li + 1) * dd, p, dtype, n, n_inexact); }
+    if (rest == "cross_attn.key.weight") { WANT(dd); return put_f16(e, e->kv_w, e->kv_w + (size_t)(2 * li) * dd, p, dtype, n, n_inexact); }
+    if (rest == "cross_attn.value.weight") { WANT(dd); return put_f16(e, e->kv_w, e->kv_w + (size_t)(2 * li + 1) * dd, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.value.bias") { WANT(d); return put_f32(e->kv_b + (size_t)(2 * li + 1) * d, p, dtype, n); }
-    if (rest == "cross_attn.out.weight") { WANT(dd); return put_f16(l.co_w, p, dtype, n, n_inexact); }
+    if (rest == "cross_attn.out.weight") { WANT(dd); return put_f16(e, l.co_w, l.co_w, p, dtype, n, n_inexact); }
     if (rest == "cross_attn.out.bias") { WANT(d); return put_f32(l.co_b, p, dtype, n); }
     if (rest == "cross_attn_ln.weight") { WANT(d); return put_f32(l.lnc_g, p, dtype, n); }
     if (rest == "cross_attn_ln.bias") { WANT(d); return put_f32(l.lnc_b, p, dtype, n); }
@@ -744,6 +828,21 @@ int run_encoder(wca_engine* e, int B) {
     g.gelu = 1;
     g.out_mode = cv ? 4 : 0;
     g.site = 3;
+    if (cv && use_wlo(e) && e->wlo_bases.count(e->conv1_w)) {   // inexact conv1 weights: the A_hi W_lo^T term, added before the GELU
+      GemmArgs x = g;
+      x.W = e->sw.conv1_wlo;
+      x.bias = nullptr;
+      x.gelu = 0;
+      x.out_mode = 1;
+      x.c_lo = 0;
+      x.c_rows_per_batch = 0;
+      HIPCHK(e->wlo_tmp[0].ensure((size_t)g.M * g.N * sizeof(float)));
+      x.C = e->wlo_tmp[0].p;
+      x.ldc = g.N;
+      HIPCHK(launch_gemm(x, s));
+      g.addend = (const float*)e->wlo_tmp[0].p;
+      g.ld_addend = g.N;
+    }
     HIPCHK(launch_gemm(g, s));
   }
   {
@@ -765,6 +864,20 @@ int run_encoder(wca_engine* e, int B) {
     g.gelu = 1;
     g.out_mode = 1;
     g.site = 3;
+    if (cv && use_wlo(e) && e->wlo_bases.count(e->conv2_w)) {
+      GemmArgs x = g;
+      x.W = e->sw.conv2_wlo;
+      x.bias = nullptr;
+      x.pos = nullptr;
+      x.gelu = 0;
+      x.out_mode = 1;
+      HIPCHK(e->wlo_tmp[0].ensure((size_t)g.M * g.N * sizeof(float)));
+      x.C = e->wlo_tmp[0].p;
+      x.ldc = g.N;
+      HIPCHK(launch_gemm(x, s));
+      g.addend = (const float*)e->wlo_tmp[0].p;
+      g.ld_addend = g.N;
+    }
     HIPCHK(launch_gemm(g, s));
   }
   const int M = B * N_CTX;
@@ -793,7 +906,7 @@ int run_encoder(wca_engine* e, int B) {
     // q / k / v projection: xn is a pair buffer iff this layer's GEMMs are split (its LayerNorm wrote it for them)
     const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d, M, 3 * d, as ? 4 : 0);
     mark(WCA_SITE_QKV, li, 0);
-    HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0, oq.a_lo));
+    HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0, oq.a_lo, e, oq.Wp, oq.Kp));
     mark(WCA_SITE_QKV, li, 1);
     AttnArgs a{};
     a.Q = e->qkv;
@@ -820,18 +933,18 @@ int run_encoder(wca_engine* e, int B) {
     // layer's attn_ln / ln_post = LN1[li + 1]
     const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d, M, d, 2);
     if (int rc = gemm_residual_ln(e, s, e->att, oo.lda, oo.W, oo.ldw, l.out_b, e->x, M, d, oo.K, l.ln2_g, l.ln2_b, e->xn, gs, 1, e->fuse_ln, WCA_SITE_OUT, li,
-                                  WCA_SITE_LN2, li, oo.a_lo))
+                                  WCA_SITE_LN2, li, oo.a_lo, oo.Wp, oo.Kp))
       return rc;
     const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d, M, 4 * d, gs ? 4 : 0);
     mark(WCA_SITE_FC1, li, 0);
-    HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0, o1.a_lo));
+    HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0, o1.a_lo, e, o1.Wp, o1.Kp));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
     // the LayerNorm behind fc2 feeds the next layer's q / k / v projection, or (ln_post) the cross-K/V projection
     const bool next_pair = last ? site_on(e, WCA_PSITE_CROSS_KV) : enc_gemm_split(e, li + 1);
     const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d, M, d, 2);
     if (int rc = gemm_residual_ln(e, s, e->hid, o2.lda, o2.W, o2.ldw, l.fc2_b, e->x, M, d, o2.K, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
-                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1, o2.a_lo))
+                                  last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1, o2.a_lo, o2.Wp, o2.Kp))
       return rc;
   }
   return WCA_OK;
@@ -849,7 +962,7 @@ int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v
   const bool ks = site_on(e, WCA_PSITE_CROSS_KV), cs = site_on(e, WCA_PSITE_CAPTURE);
   const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d, B * N_CTX, n_cols, cs ? 4 : 0);
   HIPCHK(gemm(e->stream, e->xn, o.lda, o.W, o.ldw, e->kv_b, kvbuf, (cs ? 2 : 1) * L * 2 * dt, B * N_CTX, n_cols, o.K, 0, 0, 3, nullptr, 0,
-              cs ? (long)L * 2 * dt : 0, o.a_lo));
+              cs ? (long)L * 2 * dt : 0, o.a_lo, e, o.Wp, o.Kp));
   return WCA_OK;
 }
 
@@ -866,7 +979,8 @@ int run_decoder_sites(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
   const int omg = gs ? 2 : 1, omx = cs ? 2 : 1;
   const int kv_ld = omx * L * 2 * dt;
   const long kv_lo = (long)L * 2 * dt;
-  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s));
+  HIPCHK(launch_embed(tokens_dev, e->tok_emb, e->dec_pos, e->xd, B, n, dt, D.n_vocab, e->err_dev, s,
+                      (gs && use_wlo(e) && e->wlo_bases.count(e->tok_emb)) ? wlo_of(e, e->tok_emb) : nullptr));
   auto ln = [&](const float* g, const float* b) -> int {
     HIPCHK(launch_layernorm_f16(e->xd, g, b, e->xdn, M, dt, 1e-5f, s, omg * dt, gs ? dt : 0));
     return WCA_OK;
@@ -875,7 +989,7 @@ int run_decoder_sites(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
   auto mm = [&](const half_t* A, bool a_pair, const half_t* W1, const half_t* W2, const float* bias, void* C, int ldc, int N, int K, int gelu, int out_mode,
                 long c_lo, int site) -> int {
     const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K, M, N, (c_lo > 0 && out_mode == 0) ? 4 : out_mode);
-    HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo, o.a_lo));
+    HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo, o.a_lo, e, o.Wp, o.Kp));
     return WCA_OK;
   };
   for (int li = 0; li < L; ++li) {
@@ -1107,17 +1221,6 @@ int run_decode_step(wca_engine* e, hipStream_t s, int ws, const half_t* kvbuf, c
 int check_ready(wca_engine* e) {
   if (!e) return fail(WCA_ERR_INVALID, "null engine");
   if (!e->finalized) return fail(WCA_ERR_STATE, "weights not finalized (call wca_finalize_weights)");
-  // the pair sites compute the reference's fp32 forward only on weights that are EXACT in f16 (every openai checkpoint); never run a
-  // narrower model silently: refuse, unless the caller accepted the rounding
-  if (e->sites != 0 && !e->inexact.empty() && !e->allow_rounded) {
-    size_t tot = 0;
-    for (const auto& kv : e->inexact) tot += kv.second;
-    return fail(WCA_ERR_INVALID,
-                "the reference-precision mode needs weights that are exact in f16 (f16 at rest, like openai checkpoints): %zu tensor(s) hold %zu "
-                "fp32 value(s) that f16 storage rounded (first: %s, %zu values). Re-load an f16 checkpoint, call wca_set_allow_rounded_weights(e, 1) "
-                "to run the pair arithmetic on the ROUNDED weights (not the fp32 model's arithmetic), or wca_set_precision(e, WCA_PRECISION_F16)",
-                e->inexact.size(), tot, e->inexact.begin()->first.c_str(), e->inexact.begin()->second);
-  }
   HIPCHK(hipSetDevice(e->device));
   return ensure_split_weights(e);  // split mode: the K-doubled weight copies are current (no-op otherwise)
 }
@@ -1459,6 +1562,9 @@ void wca_engine_destroy(wca_engine* e) {
   e->coll_recv.release();
   if (e->wslab) (void)hipFree(e->wslab);
   if (e->wslab2) (void)hipFree(e->wslab2);
+  if (e->wslab_lo) (void)hipFree(e->wslab_lo);
+  e->wlo_tmp[0].release();
+  e->wlo_tmp[1].release();
   if (e->aslab) (void)hipFree(e->aslab);
   if (e->meta_host) (void)hipHostFree(e->meta_host);
   if (e->err_host) (void)hipHostFree(e->err_host);
@@ -1755,13 +1861,13 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     rc = WCA_OK;
   } else if (name == "encoder.conv1.weight") {
     WANTN((size_t)d * D.n_mels * 3);
-    rc = put_conv(e->conv1_w, p, dtype, d, D.n_mels, e->k1pad, &n_inexact);
+    rc = put_conv(e, e->conv1_w, p, dtype, d, D.n_mels, e->k1pad, &n_inexact);
   } else if (name == "encoder.conv1.bias") {
     WANTN(d);
     rc = put_f32(e->conv1_b, p, dtype, n);
   } else if (name == "encoder.conv2.weight") {
     WANTN((size_t)d * d * 3);
-    rc = put_conv(e->conv2_w, p, dtype, d, d, 3 * d, &n_inexact);
+    rc = put_conv(e, e->conv2_w, p, dtype, d, d, 3 * d, &n_inexact);
   } else if (name == "encoder.conv2.bias") {
     WANTN(d);
     rc = put_f32(e->conv2_b, p, dtype, n);
@@ -1776,7 +1882,7 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     rc = put_f32(e->lnpost_b, p, dtype, n);
   } else if (name == "decoder.token_embedding.weight") {
     WANTN((size_t)D.n_vocab * dt);
-    rc = put_f16(e->tok_emb, p, dtype, n, &n_inexact);
+    rc = put_f16(e, e->tok_emb, e->tok_emb, p, dtype, n, &n_inexact);
   } else if (name == "decoder.positional_embedding") {
     WANTN((size_t)D.n_text_ctx * dt);
     rc = put_f32(e->dec_pos, p, dtype, n);
@@ -1802,6 +1908,7 @@ int wca_load_weight(wca_engine* e, const char* name_c, const void* p, int dtype,
     e->sw_dirty = true;
     if (n_inexact) e->inexact[name] = n_inexact;
     else e->inexact.erase(name);
+    if (e->inexact.empty()) e->wlo_bases.clear();   // (every remainder in the W_lo slab is zero again)
   }
   return rc < 0 ? rc : WCA_OK;  // unknown names (e.g. alignment_heads) are ignored
 }

@@ -56,6 +56,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x4 (&acc)[MT][4],
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
+    if (OUT_MODE != 2 && a.addend != nullptr) {   // pre-activation addend (kernels.h)
+      const float* ap = a.addend + (long)m * a.ld_addend + nb;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (nb + j < a.N) v[j] += ap[j];
+    }
     if (GELU) {
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {
@@ -949,7 +955,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
   // M <= 64 (greedy-decode steps): weight-streaming skinny kernel; force_tile 64 forces it, 128 etc. bypass it
   if (a.out_mode == 4 && (a.c_lo <= 0 || (a.c_lo & 7))) return hipErrorInvalidValue;
-  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.out_mode != 4 && a.a_lo <= 0) {
+  if (a.addend != nullptr && (a.out_mode == 2 || a.out_mode == 3)) return hipErrorInvalidValue;   // (accumulating modes take the extra term as a second accumulating launch)
+  if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.addend == nullptr && a.out_mode != 4 && a.a_lo <= 0) {
     const dim3 sgrid((unsigned)((a.N + 15) / 16)), sblock(256);
 #define WCA_LAUNCH_SK(OM, G) hipLaunchKernelGGL((gemm_skinny_f16_kernel<OM, G>), sgrid, sblock, 0, s, a)
     if (a.out_mode == 0) {

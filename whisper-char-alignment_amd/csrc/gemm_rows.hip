@@ -348,7 +348,7 @@ bool gemm_rows_supported(int M, int N, int K, bool layernorm_a) {
 hipError_t launch_gemm_rows(const GemmArgs& a_in, hipStream_t s) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0) return hipSuccess;
-  if (a.K <= 0 || a.a_rows_per_batch != 0 || a.pos != nullptr) return hipErrorInvalidValue;
+  if (a.K <= 0 || a.a_rows_per_batch != 0 || a.pos != nullptr || a.addend != nullptr) return hipErrorInvalidValue;
   if (a.splitk <= 0) a.splitk = gemm_rows_pick_splitk(a.K);
   if (a.splitk <= 0 || a.K % (a.splitk * 128) != 0 || a.K / a.splitk > 1024) return hipErrorInvalidValue;
   if ((a.ldw % 8) != 0) return hipErrorInvalidValue;

@@ -33,6 +33,9 @@ struct GemmArgs {
   int c_rows_per_batch;    // 0 => flat
   long c_batch_stride;     // elements
   long c_lo;               // out_mode 4: elements from a value's hi half to its lo half (a multiple of 8)
+  const float* addend;     // optional PRE-activation addend addend[m * ld_addend + n] (f32): added to the accumulator (with the bias) before GELU / the store --
+                           // the A_hi W_lo^T term of a weight matrix that is not exact in f16 (engine.hip, W_lo slab); out_mode 0 / 1 / 4 of the tile kernels
+  int ld_addend;
   const float* pos;        // optional additive table pos[(m % pos_period)][N] (f32), or nullptr
   int pos_period;
   int M, N, K;             // K % 64 == 0
@@ -119,8 +122,9 @@ hipError_t launch_layernorm_f16(const float* x, const float* gamma, const float*
                                 int rows, int d, float eps, hipStream_t s, int ld_out = 0, long lo_off = 0);
 // x[b*n + i][:] = tok_emb[tokens[b*n+i]][:] + pos_emb[i][:]
 // ids outside [0, n_vocab) are embedded as token 0 and raise *err (device int, nullable)
+// tok_emb_lo (nullable): the lo halves of an embedding table that is not exact in f16 (value = hi + lo)
 hipError_t launch_embed(const int64_t* tokens, const half_t* tok_emb, const float* pos_emb, float* x,
-                        int B, int n, int d, int n_vocab, int* err, hipStream_t s);
+                        int B, int n, int d, int n_vocab, int* err, hipStream_t s, const half_t* tok_emb_lo = nullptr);
 hipError_t launch_fill_f16(half_t* p, size_t n, float v, hipStream_t s);
 
 // ---------------------------------------------------------------- greedy ASR decode steps (decode.hip)
