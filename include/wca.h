@@ -113,11 +113,13 @@ int wca_load_weight(wca_engine* e, const char* name, const void* host_ptr, int d
 int wca_finalize_weights(wca_engine* e);
 /* Weight MATRICES (Linear / Conv1d weights, the token embedding) are stored f16, like every openai checkpoint at rest
  * (/root/reference/infer_ali.py:36-37: whisper.load_model upcasts those f16 values to fp32 parameters); biases, LayerNorm parameters and
- * positional embeddings stay fp32. An fp32 source tensor whose values are NOT f16-representable (a fine-tuned fp32 state dict) is rounded
- * by that storage, and the pair arithmetic of the contract mode is then no longer the fp32 model's: wca_load_weight counts such elements
- * per tensor (wca_weights_inexact: tensors, values, name of the first one), and while any precision site is on pairs every entry point
- * that runs the model returns WCA_ERR_INVALID with that count -- never a silently narrower model. wca_set_allow_rounded_weights(e, 1) is
- * the explicit opt-in to run on the rounded weights; the f16 mode (approximate by definition) always runs. */
+ * positional embeddings stay fp32. An fp32 source tensor whose values are NOT f16-representable (a fine-tuned fp32 state dict, which the
+ * reference runs in true fp32) is not rounded away: wca_load_weight keeps the remainder lo = f16(w - f16(w)) of every such element in a second
+ * slab (w = hi + lo to 2^-22 |w|, the representation the activations travel in) and counts the elements per tensor (wca_weights_inexact:
+ * tensors, values, name of the first one). While a precision site is on pairs its GEMMs multiply the extra term A_hi W_lo^T for those
+ * matrices (one more f16 pass: an accumulating launch for the residual GEMMs, a pre-activation addend for the others; the embedding adds
+ * hi + lo) -- slower, never a narrower model. wca_set_allow_rounded_weights(e, 1) drops the remainders (the engine then computes what the
+ * f16-rounded checkpoint computes); the f16 mode (approximate by definition) ignores them. */
 int wca_weights_inexact(wca_engine* e, long long* n_tensors_out, long long* n_values_out, char* first_name_out, int first_name_cap);
 int wca_set_allow_rounded_weights(wca_engine* e, int on);
 

@@ -289,9 +289,11 @@ struct GemmOpnd {
   const half_t* Wp;   // the plain [N][K] matrix when the product is a PAIR product (null otherwise): where the W_lo term of an inexact matrix comes from
   int Kp;
 };
-inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K, int M = 0, int N = 0, int out_mode = 0) {
+inline GemmOpnd pick_operands(bool a_pair, bool want, const half_t* W1, const half_t* W2, int K, int M = 0, int N = 0, int out_mode = 0, const wca_engine* wlo_e = nullptr) {
   const bool use = a_pair && want;
-  if (use && M > 0 && gemm_splitw_supported(M, N, K, 2 * K, out_mode)) return GemmOpnd{W1, 2 * K, K, K, (long)K, W1, K};
+  // (a matrix with a W_lo remainder takes the K-doubled call for its non-accumulating products: their extra term enters through the generic epilogue's addend)
+  const bool no_splitw = wlo_e != nullptr && out_mode != 2 && use_wlo(wlo_e) && wlo_e->wlo_bases.count(W1) != 0;
+  if (use && !no_splitw && M > 0 && gemm_splitw_supported(M, N, K, 2 * K, out_mode)) return GemmOpnd{W1, 2 * K, K, K, (long)K, W1, K};
   return GemmOpnd{use ? W2 : W1, a_pair ? 2 * K : K, use ? 2 * K : K, use ? 2 * K : K, 0, use ? W1 : nullptr, K};
 }
 
@@ -904,7 +906,7 @@ int run_encoder(wca_engine* e, int B) {
     const LayerW& w2 = e->split ? e->sw.enc[li] : l;  // the K-doubled copies [N][2K] = [W | W] (present while any site is split)
     const int oma = as ? 2 : 1;  // q / k / v rows and the attention output: pairs iff the attention is split
     // q / k / v projection: xn is a pair buffer iff this layer's GEMMs are split (its LayerNorm wrote it for them)
-    const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d, M, 3 * d, as ? 4 : 0);
+    const GemmOpnd oq = pick_operands(gs, gs, l.qkv_w, w2.qkv_w, d, M, 3 * d, as ? 4 : 0, e);
     mark(WCA_SITE_QKV, li, 0);
     HIPCHK(gemm(s, e->xn, oq.lda, oq.W, oq.ldw, l.qkv_b, e->qkv, oma * 3 * d, M, 3 * d, oq.K, 0, 0, 1, nullptr, 0, as ? 3 * d : 0, oq.a_lo, e, oq.Wp, oq.Kp));
     mark(WCA_SITE_QKV, li, 1);
@@ -931,18 +933,18 @@ int run_encoder(wca_engine* e, int B) {
     mark(WCA_SITE_ATTN, li, 1);
     // sites OUT / FC2 = the GEMM alone (or the fused GEMM + LayerNorm kernel); the LayerNorm launches: mlp_ln = LN2[li], the next
     // layer's attn_ln / ln_post = LN1[li + 1]
-    const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d, M, d, 2);
+    const GemmOpnd oo = pick_operands(as, gs, l.out_w, w2.out_w, d, M, d, 2, e);
     if (int rc = gemm_residual_ln(e, s, e->att, oo.lda, oo.W, oo.ldw, l.out_b, e->x, M, d, oo.K, l.ln2_g, l.ln2_b, e->xn, gs, 1, e->fuse_ln, WCA_SITE_OUT, li,
                                   WCA_SITE_LN2, li, oo.a_lo, oo.Wp, oo.Kp))
       return rc;
-    const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d, M, 4 * d, gs ? 4 : 0);
+    const GemmOpnd o1 = pick_operands(gs, gs, l.fc1_w, w2.fc1_w, d, M, 4 * d, gs ? 4 : 0, e);
     mark(WCA_SITE_FC1, li, 0);
     HIPCHK(gemm(s, e->xn, o1.lda, o1.W, o1.ldw, l.fc1_b, e->hid, (gs ? 2 : 1) * 4 * d, M, 4 * d, o1.K, 1, 0, 1, nullptr, 0, gs ? 4 * d : 0, o1.a_lo, e, o1.Wp, o1.Kp));
     mark(WCA_SITE_FC1, li, 1);
     const bool last = li + 1 == D.n_audio_layer;
     // the LayerNorm behind fc2 feeds the next layer's q / k / v projection, or (ln_post) the cross-K/V projection
     const bool next_pair = last ? site_on(e, WCA_PSITE_CROSS_KV) : enc_gemm_split(e, li + 1);
-    const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d, M, d, 2);
+    const GemmOpnd o2 = pick_operands(gs, gs, l.fc2_w, w2.fc2_w, 4 * d, M, d, 2, e);
     if (int rc = gemm_residual_ln(e, s, e->hid, o2.lda, o2.W, o2.ldw, l.fc2_b, e->x, M, d, o2.K, last ? e->lnpost_g : e->enc[li + 1].ln1_g,
                                   last ? e->lnpost_b : e->enc[li + 1].ln1_b, e->xn, next_pair, 4, e->fuse_ln, WCA_SITE_FC2, li, WCA_SITE_LN1, li + 1, o2.a_lo, o2.Wp, o2.Kp))
       return rc;
@@ -960,7 +962,7 @@ int run_cross_kv(wca_engine* e, int B, half_t* kvbuf = nullptr, bool skip_last_v
   const int d = D.n_audio_state, dt = D.n_text_state, L = D.n_text_layer;
   const int n_cols = L * 2 * dt - (skip_last_v ? dt : 0);
   const bool ks = site_on(e, WCA_PSITE_CROSS_KV), cs = site_on(e, WCA_PSITE_CAPTURE);
-  const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d, B * N_CTX, n_cols, cs ? 4 : 0);
+  const GemmOpnd o = pick_operands(ks, ks, e->kv_w, e->split ? e->sw.kv_w : e->kv_w, d, B * N_CTX, n_cols, cs ? 4 : 0, e);
   HIPCHK(gemm(e->stream, e->xn, o.lda, o.W, o.ldw, e->kv_b, kvbuf, (cs ? 2 : 1) * L * 2 * dt, B * N_CTX, n_cols, o.K, 0, 0, 3, nullptr, 0,
               cs ? (long)L * 2 * dt : 0, o.a_lo, e, o.Wp, o.Kp));
   return WCA_OK;
@@ -988,7 +990,7 @@ int run_decoder_sites(wca_engine* e, const int64_t* tokens_dev, int B, int n, fl
   // C = A W^T (+ bias ...): a_pair = the A buffer holds [hi | lo] rows of K values each; c_lo > 0: f16 pair output
   auto mm = [&](const half_t* A, bool a_pair, const half_t* W1, const half_t* W2, const float* bias, void* C, int ldc, int N, int K, int gelu, int out_mode,
                 long c_lo, int site) -> int {
-    const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K, M, N, (c_lo > 0 && out_mode == 0) ? 4 : out_mode);
+    const GemmOpnd o = pick_operands(a_pair, gs, W1, W2, K, M, N, (c_lo > 0 && out_mode == 0) ? 4 : out_mode, e);
     HIPCHK(gemm(s, A, o.lda, o.W, o.ldw, bias, C, ldc, M, N, o.K, gelu, out_mode, site, e->sk_big[1], e->sk_big_bytes, c_lo, o.a_lo, e, o.Wp, o.Kp));
     return WCA_OK;
   };

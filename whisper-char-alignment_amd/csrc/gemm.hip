@@ -955,7 +955,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   if ((a.lda % 8) != 0 || (a.ldw % 8) != 0) return hipErrorInvalidValue;  // 16-byte LDS-DMA source chunks
   // M <= 64 (greedy-decode steps): weight-streaming skinny kernel; force_tile 64 forces it, 128 etc. bypass it
   if (a.out_mode == 4 && (a.c_lo <= 0 || (a.c_lo & 7))) return hipErrorInvalidValue;
-  if (a.addend != nullptr && (a.out_mode == 2 || a.out_mode == 3)) return hipErrorInvalidValue;   // (accumulating modes take the extra term as a second accumulating launch)
+  if (a.addend != nullptr && (a.out_mode == 2 || a.out_mode == 3 || a.a_lo > 0)) return hipErrorInvalidValue;   // (accumulating modes take the extra term as a second
+                                                                                                                // accumulating launch; with an addend the pair product is the K-doubled call)
   if ((a.force_tile == 64 || a.force_tile == 0) && a.M <= 64 && (a.K % 512) == 0 && a.a_rows_per_batch == 0 && a.pos == nullptr && a.addend == nullptr && a.out_mode != 4 && a.a_lo <= 0) {
     const dim3 sgrid((unsigned)((a.N + 15) / 16)), sblock(256);
 #define WCA_LAUNCH_SK(OM, G) hipLaunchKernelGGL((gemm_skinny_f16_kernel<OM, G>), sgrid, sblock, 0, s, a)
@@ -998,7 +999,8 @@ hipError_t launch_gemm(const GemmArgs& a_in, hipStream_t s) {
   // pair operands on the persistent kernel: three A slots + one W slot (round 5); the switch gemm_ring = 1 keeps round 4's two-slot rings (A/B, tests)
   const int ring = splitw ? (debug_switch(DBG_GEMM_RING) == 1 ? 1 : 2) : 0;
   const bool want_big = (a.force_tile == 256 || a.force_tile == 257 || a.force_tile == 258) || (a.force_tile == 0 && tiles256 >= 192);
-  const bool pipelined = want_big && can_buf && a.force_tile != 256;
+  const bool pipelined = want_big && can_buf && a.force_tile != 256 && a.addend == nullptr;   // (the pre-activation addend lives in the generic epilogue only: the
+                                                                                                 //  persistent kernel's epilogue stays as it is -- an addend launch takes the two-barrier 256 x 256 kernel)
   const bool big = want_big;
   dim3 grid, block;
   size_t shmem;

@@ -83,19 +83,6 @@ __device__ __forceinline__ void epilogue_wide(const ArgsT& a, f32x4 (&acc)[8][4]
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[nt * 4 + r] = acc[mt][nt][r] + bv[nt * 4 + r];
     if (m >= a.M) continue;
-    if (OUT_MODE != 2 && a.addend != nullptr) {   // pre-activation addend (the A_hi W_lo^T term of an inexact weight matrix): wave-uniform, absent on the usual path
-      const float* ap = a.addend + (long)m * a.ld_addend + nbase;
-      asm volatile("" : "+v"(ap));   // (a per-lane address from here on: without this hipcc 7.2 dies with "illegal VGPR to SGPR copy" in some instantiations)
-      const int n_lim = a.N - nbase;
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int cidx = col[nt] + r;
-          const float add = ap[cidx < n_lim ? cidx : 0];
-          v[nt * 4 + r] += cidx < n_lim ? add : 0.f;
-        }
-    }
     if (GELU) {
 #pragma unroll
       for (int j = 0; j < 16; j += 2) {

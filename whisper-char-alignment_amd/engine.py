@@ -239,19 +239,16 @@ class WhisperAMD:
     def load_state_dict(self, sd, allow_rounded_weights=False):
         """sd: openai-whisper naming (encoder.blocks.0.attn.query.weight ...), torch tensors or numpy arrays.
         Weight matrices are stored f16 (every openai checkpoint is f16 at rest; whisper.load_model upcasts those values,
-        /root/reference/infer_ali.py:36-37). An fp32 state dict whose values are NOT f16-representable would be rounded by that: in the
-        contract mode this raises (never a silently narrower model) unless allow_rounded_weights=True; the f16 mode always loads.
-        `weights_inexact` reports what was rounded."""
+        /root/reference/infer_ali.py:36-37). An fp32 state dict whose values are NOT f16-representable (a fine-tuned fp32 checkpoint, which the
+        reference runs in true fp32) keeps the remainders f16(w - f16(w)) in a second slab and the contract mode multiplies the extra term
+        A_hi W_lo^T -- the same hi + lo representation the activations travel in; slower (one more f16 pass per affected GEMM), never narrower.
+        allow_rounded_weights=True skips that term (the engine then computes what the f16-ROUNDED checkpoint computes). `weights_inexact` reports
+        what was not exact; the f16 mode ignores the remainders (it is approximate by definition)."""
         _lib.check(self._lib.wca_set_allow_rounded_weights(self._h, 1 if allow_rounded_weights else 0))
         for name, t in sd.items():
             self._load_one(name, t)
         _lib.check(self._lib.wca_finalize_weights(self._h))
         self._finalized = True
-        n_t, n_v, first = self.weights_inexact
-        if n_t and not allow_rounded_weights and self.precision != "f16":
-            raise ValueError("%d weight tensor(s) hold %d fp32 value(s) that are not f16-representable (first: %s): the contract precision mode "
-                             "computes the reference's fp32 forward only on weights that are exact in f16. Pass allow_rounded_weights=True to run "
-                             "on the rounded weights, or precision='f16'." % (n_t, n_v, first))
         return self
 
     @property
@@ -268,8 +265,8 @@ class WhisperAMD:
         whisper.load_model(name), installs the official alignment heads of `name` (inferred from the dimensions when
         they identify the model; large-v1 / large-v2 need the name). This is the drop-in's `whisper.load_model`: the model comes
         back in the CONTRACT precision mode ('reference': the fp32 forward of timing.py:58 to fp32 summation noise), like a bare
-        WhisperAMD(); precision='f16' opts out. A checkpoint whose fp32 weights are not f16-representable raises unless
-        allow_rounded_weights=True (load_state_dict)."""
+        WhisperAMD(); precision='f16' opts out. A checkpoint whose fp32 weights are not f16-representable runs with its remainder slab
+        (load_state_dict); allow_rounded_weights=True drops the remainders."""
         ck = torch.load(path, map_location="cpu")
         dims = ModelDimensions(**ck["dims"])
         m = cls(dims, device=device, max_batch=max_batch, precision=precision)
