@@ -245,9 +245,9 @@ struct wca_engine {
   bool overlap = true;       // phase 2 on its own stream (false: everything on `stream`, for clean per-kernel profiles)
   int part_cus = 0;          // wca_set_cu_partition: > 0 = phase 2 / the decode loop own that many CUs (CU-masked streams), phase 1 the rest
   hipStream_t part_s1 = nullptr, part_s2 = nullptr, part_s3 = nullptr;  // the masked streams: they REPLACE stream / stream2 / stream3 while active
-  hipStream_t saved_s2 = nullptr, saved_s3 = nullptr;
+  hipStream_t saved_s2 = nullptr, saved_s3 = nullptr;                   // ... and the engine's own ones come back when the partition is lifted
   hipStream_t user_stream = nullptr;   // the stream the caller bound last (wca_engine_set_stream), also while a partition is active
-  bool user_stream_set = false;                   // ... and the engine's own ones come back when the partition is lifted
+  bool user_stream_set = false;
   bool dec_fused = true;     // few-row GEMM with LayerNorm prologue / KV append / split-K for M <= DEC_ROWS_MAX = 128 rows (wca_set_decode_mode)
   int dec_streams = 1;       // 2: the greedy decode loop as two half-batches on two streams (measured: the two queues' kernels run
                              // back to back, not concurrently -- 3.86 vs 3.90 ms per step -- so one stream is the default)
@@ -1471,7 +1471,7 @@ int ensure_res_host(wca_engine* e, int slot, size_t ints) {
 extern "C" {
 
 const char* wca_last_error(void) { return g_err.c_str(); }
-int wca_version(void) { return 1; }
+int wca_version(void) { return 5; }   // (round 5: a new engine is in the contract mode; wca_engine_create_ex, W_lo slab, switch table)
 
 int wca_engine_create(const wca_model_dims* dims, int device_ordinal, int max_batch, wca_engine** out) {
   return wca_engine_create_ex(dims, device_ordinal, max_batch, WCA_PRECISION_REFERENCE, out);   // the CONTRACT mode is the default (round 5)
