@@ -589,3 +589,30 @@ def test_w_lo_term_on_the_bench_sized_kernels(wca):
     del m, m_r
 
 
+
+
+def test_pair_gemm_ring_race_screen(eng, lib, wca, switch):
+    """A new synchronisation structure is screened for races (cdna_hip_programming.md, "a sync-structure edit makes a NEW template"): the three-A-slot ring of the pair GEMM
+    (A tile requested two steps ahead and left in flight across the step's barrier by a counted vmcnt) on shapes with many tiles per workgroup and ragged edges, 40 launches
+    each while a second stream keeps the memory system busy -- every launch must give the bits of round 4's two-slot rings."""
+    side = torch.cuda.Stream()
+    noise_a = torch.randn(64 * 1024 * 1024 // 4, device="cuda")
+    for M, N, K in ((24064, 3072, 1024), (30000, 1024, 512), (17000, 2300, 128)):
+        g = torch.Generator().manual_seed(M + N)
+        a2 = _split((torch.randn(M, K, generator=g) * 0.7).cuda())
+        w = (torch.randn(N, K, generator=g) * 0.1).half().cuda()
+        bias = torch.randn(N, generator=g).cuda()
+        switch("gemm_ring", 1)
+        want = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(want), M, N, K, 0, 1))
+        torch.cuda.synchronize()
+        switch("gemm_ring", 0)
+        out = torch.empty_like(want)
+        for it in range(40):
+            out.fill_(float("nan"))
+            with torch.cuda.stream(side):
+                noise_b = noise_a * 1.0001 + float(it)   # unrelated traffic beside the launch
+            wca._lib.check(lib.wca_test_gemm_pairs(eng._h, _vp(a2), _vp(w), _vp(bias), _vp(out), M, N, K, 0, 1))
+            torch.cuda.synchronize()
+            assert torch.equal(out, want), (M, N, K, it)
+        del noise_b
